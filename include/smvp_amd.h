@@ -1,0 +1,239 @@
+/*
+ * smvp_amd.h -- C ABI of the MI355X-native SpMV engine (libsmvp_amd.so).
+ *
+ * This is the drop-in boundary for smvp-toolkit's CSR / TJDS path.  The
+ * reference has no plugin or FFI layer: its boundary is the pair of C functions
+ * main() calls (main-cli.c:325 smvp_csr_compute, main-cli.c:734
+ * smvp_tjds_compute) plus the Matrix Market reader and the report writer around
+ * them.  Each entry point below names the reference interface it replaces.
+ * Paths are relative to the reference checkout (smvp-toolkit v0.6.4).
+ *
+ * Conventions
+ *   - plain C types only; every function returns an int status (0 = SMVP_OK);
+ *     the reference's functions cannot fail and its CLI exits on error, so the
+ *     CLI in smvp-toolkit_amd/cli maps these codes onto the same messages.
+ *   - indices are 32-bit `int`, values `double`, exactly like the reference
+ *     (main-cli.c:42-47, 61-75).
+ *   - inputs are never modified (the reference sorts the caller's COO array in
+ *     place, main-cli.c:340,766) and outputs go to caller-owned buffers (the
+ *     reference returns a malloc'd y it never frees, main-cli.c:370,468).
+ *   - "d_" pointers are device (HBM) addresses, `stream` is a hipStream_t passed
+ *     as void* (NULL = the null stream).  A handle belongs to one device; calls
+ *     on different handles are independent, calls on one handle are not
+ *     re-entrant.
+ *   - there is no CPU fallback: compute entry points return
+ *     SMVP_ERR_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef SMVP_AMD_H
+#define SMVP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMVP_VERSION_MAJOR 0
+#define SMVP_VERSION_MINOR 6
+#define SMVP_VERSION_REVISION 4 /* report header keeps the reference's version string, main-cli.c:7-9,294 */
+
+/* ------------------------------------------------------------------ status */
+enum {
+    SMVP_OK = 0,
+    SMVP_ERR_INVALID = 1,     /* bad argument / inconsistent arrays */
+    SMVP_ERR_NO_DEVICE = 2,   /* no usable HIP device: the product has no CPU path */
+    SMVP_ERR_HIP = 3,         /* a HIP runtime call failed (see smvp_last_error) */
+    SMVP_ERR_ALLOC = 4,
+    SMVP_ERR_IO = 5,
+    SMVP_ERR_UNSUPPORTED = 6,
+    /* Matrix Market codes keep mmio's numbers (mmio/mmio.h:75-81) */
+    SMVP_MM_COULD_NOT_READ_FILE = 11,
+    SMVP_MM_PREMATURE_EOF = 12,
+    SMVP_MM_NOT_MTX = 13,
+    SMVP_MM_NO_HEADER = 14,
+    SMVP_MM_UNSUPPORTED_TYPE = 15,
+    SMVP_MM_LINE_TOO_LONG = 16,
+    SMVP_MM_COULD_NOT_WRITE_FILE = 17
+};
+const char *smvp_last_error(void);     /* thread-local text of the last failure */
+const char *smvp_version_string(void); /* "0.6.4" */
+
+/* -------------------------------------------------------------------- types */
+/* One stored entry, 0-based.  Replaces MMRawData, main-cli.c:42-47. */
+typedef struct smvp_coo {
+    int row;
+    int col;
+    double val;
+} smvp_coo_t;
+
+/* Replaces MM_typecode (mmio/mmio.h:17): [0]='M', [1]='C'oordinate|'A'rray,
+ * [2]='R'eal|'C'omplex|'P'attern|'I'nteger, [3]='G'eneral|'S'ymmetric|'H'ermitian|s'K'ew. */
+typedef char smvp_mm_typecode[4];
+
+/* Replaces struct _time_data_ (main-cli.c:87-95) without the flexible array:
+ * the per-iteration times go to a caller-owned double[iters]. */
+typedef struct smvp_time_stats {
+    double time_total, time_avg, time_stdev, time_min, time_max; /* milliseconds */
+} smvp_time_stats_t;
+
+/* ------------------------------------------------------ Matrix Market input */
+/* Replace mm_read_banner (mmio/mmio.c:96) and mm_read_mtx_crd_size
+ * (mmio/mmio.c:180): same accepted inputs, same return codes. */
+int smvp_mm_read_banner(FILE *f, smvp_mm_typecode *matcode);
+int smvp_mm_read_mtx_crd_size(FILE *f, int *rows, int *cols, int *nnz);
+/* Replaces the entry loop in main(), main-cli.c:1426-1441: reads `nnz` entries
+ * into caller-owned storage, 1-based -> 0-based, pattern files get val = 1,
+ * symmetric storage is NOT mirrored.  A short file gives SMVP_MM_PREMATURE_EOF
+ * (the reference would carry on with uninitialised entries). */
+int smvp_mm_read_coo_entries(FILE *f, const smvp_mm_typecode matcode, int nnz, smvp_coo_t *out);
+/* Convenience for non-C callers: open + banner + size (+ entries). */
+int smvp_mm_read_header_path(const char *path, smvp_mm_typecode *matcode, int *rows, int *cols, int *nnz);
+int smvp_mm_read_coo_path(const char *path, smvp_coo_t *out, int capacity,
+                          smvp_mm_typecode *matcode, int *rows, int *cols, int *nnz);
+
+/* ------------------------------------------------------- format conversion */
+/* Replaces the CSR build inside smvp_csr_compute, main-cli.c:340-365.
+ * row_ptr[rows+1], col_ind[nnz], val[nnz]; entries ordered by (row, col) with
+ * ties kept in input order.  Bit-identical to the reference's arrays whenever
+ * the reference's are defined (no empty rows); empty rows get the standard
+ * prefix-sum row_ptr. */
+int smvp_csr_from_coo(const smvp_coo_t *coo, int rows, int nnz,
+                      int *row_ptr, int *col_ind, double *val);
+/* Replaces the TJDS build inside smvp_tjds_compute, main-cli.c:766-967.
+ * perm[cols]: original column at permuted position k (columns by length
+ * descending, ties by original index ascending, main-cli.c:209-223,868);
+ * start_pos[*num_diag + 1] with the terminator start_pos[D] = nnz always
+ * written (the reference omits it when the last diagonal has one entry,
+ * main-cli.c:951-966); row_ind[nnz], val[nnz] in (diagonal, permuted column)
+ * order.  start_pos_capacity must be >= D + 1 (rows + 1 always suffices when no
+ * (row, col) pair repeats).  Optional outputs may be NULL:
+ *   ref_num_tjdiag    the diagonal count the reference derives (main-cli.c:865:
+ *                     length of ORIGINAL column 0) -- used by ref-quirks mode;
+ *   last_diag_single  1 when the reference would leave the terminator unwritten. */
+int smvp_tjds_from_coo(const smvp_coo_t *coo, int rows, int cols, int nnz,
+                       int *perm, int *start_pos, int start_pos_capacity,
+                       int *row_ind, double *val,
+                       int *num_diag, int *ref_num_tjdiag, int *last_diag_single);
+
+/* ---------------------------------------------------------- device / engine */
+int smvp_device_count(int *count);
+int smvp_device_info(int device, char *name, size_t name_cap, int *compute_units,
+                     size_t *hbm_bytes);
+
+/* CSR kernel families (smvp_csr_set_kernel).  AUTO picks by row-length
+ * statistics at create time. */
+enum {
+    SMVP_CSR_KERNEL_AUTO = 0,
+    SMVP_CSR_KERNEL_VECTOR = 1, /* one (sub-)wavefront per row, __shfl_down sums */
+    SMVP_CSR_KERNEL_STREAM = 2  /* fixed-nnz tiles, LDS-staged segmented reduction */
+};
+enum {
+    SMVP_MEM_HOST = 0,  /* arrays are host memory: copied to the device */
+    SMVP_MEM_DEVICE = 1 /* arrays are device memory: adopted, must outlive the handle */
+};
+
+typedef struct smvp_csr smvp_csr_t;   /* device-resident CSR matrix + launch plan */
+typedef struct smvp_tjds smvp_tjds_t; /* device-resident TJDS matrix + launch plan */
+
+/* Device-side half of smvp_csr_compute (main-cli.c:343-370): the three arrays
+ * live in HBM, laid out exactly as CSRData (main-cli.c:61-66).  row_ptr is
+ * always read from the host copy as well to build the launch plan, so with
+ * SMVP_MEM_DEVICE pass the host row_ptr in `host_row_ptr` (NULL = copy it back). */
+int smvp_csr_create(smvp_csr_t **out, int device, int rows, int cols, int nnz,
+                    const int *row_ptr, const int *col_ind, const double *val,
+                    int mem_kind, const int *host_row_ptr);
+int smvp_csr_set_kernel(smvp_csr_t *h, int kernel, int param); /* param: lanes per row (VECTOR) / nnz per tile (STREAM), 0 = default */
+int smvp_csr_get_kernel(const smvp_csr_t *h, int *kernel, int *param);
+/* The timed product, main-cli.c:410-416: d_y[0..rows) = A * d_x[0..cols).  Asynchronous
+ * on `stream`; d_y is fully overwritten (no pre-zeroing needed). */
+int smvp_csr_spmv(smvp_csr_t *h, const double *d_x, double *d_y, void *stream);
+/* Name of the dominant kernel symbol of the current plan and its algorithmic
+ * byte count per launch: 12*nnz + 4*(rows+1) + 8*cols + 8*rows. */
+int smvp_csr_describe(const smvp_csr_t *h, char *kernel_name, size_t cap, double *alg_bytes);
+void smvp_csr_destroy(smvp_csr_t *h);
+
+/* Device-side half of smvp_tjds_compute (main-cli.c:756-763,944-967): val,
+ * row_ind, start_pos as TJDSData (main-cli.c:70-75) plus perm. */
+int smvp_tjds_create(smvp_tjds_t **out, int device, int rows, int cols, int nnz, int num_diag,
+                     const int *perm, const int *start_pos, const int *row_ind,
+                     const double *val, int mem_kind);
+/* Replaces the operand permutation main-cli.c:907-923: x_perm[k] = x[perm[k]],
+ * kept inside the handle.  Call again whenever x changes. */
+int smvp_tjds_set_x(smvp_tjds_t *h, const double *d_x, void *stream);
+/* The timed product, main-cli.c:1013-1020, in its corrected form
+ * y[row_ind[j]] += val[j] * x_perm[j - start_pos[d]].  d_y must be zero on
+ * entry (the reference zeroes it outside the timed window, main-cli.c:1008);
+ * smvp_tjds_zero_y does that on the same stream. */
+int smvp_tjds_zero_y(smvp_tjds_t *h, double *d_y, void *stream);
+int smvp_tjds_spmv(smvp_tjds_t *h, double *d_y, void *stream);
+/* Reference-defect emulation for parity with the committed TJDS reports
+ * (diagonal count from original column 0, missing terminator, operand indexed
+ * by row: main-cli.c:865,951-966,1018).  Host-side edit of the plan; same kernel. */
+int smvp_tjds_set_ref_quirks(smvp_tjds_t *h, int enable, int ref_num_tjdiag, int last_diag_single);
+int smvp_tjds_describe(const smvp_tjds_t *h, char *kernel_name, size_t cap, double *alg_bytes);
+void smvp_tjds_destroy(smvp_tjds_t *h);
+
+/* ------------------------------------------------ reference-shaped entry points */
+typedef struct smvp_run_opts {
+    int device;         /* HIP device ordinal */
+    int csr_kernel;     /* SMVP_CSR_KERNEL_* */
+    int csr_param;      /* 0 = default */
+    int tjds_ref_quirks;/* 1: reproduce the reference's defective TJDS output */
+    int use_graph;      /* 1: replay the product from a hipGraph (per-iteration timing kept) */
+    const double *x;    /* host operand, NULL = all ones (main-cli.c:368-369) */
+} smvp_run_opts_t;
+void smvp_run_opts_default(smvp_run_opts_t *o);
+
+/* Replaces  double *smvp_csr_compute(MMRawData*, int rows, int nnz, int iters,
+ *                                    struct _time_data_*)      main-cli.c:325-469
+ * COO in -> CSR build -> upload -> `iters` products, each timed on its own with
+ * hipEvents around the product only (the reference's clock_gettime window,
+ * main-cli.c:408-419) -> y[rows] and time_each_ms[iters] out, stats reduced as
+ * main-cli.c:428-456.  `cols` is new: the reference assumes a square matrix. */
+int smvp_csr_compute(const smvp_coo_t *coo, int rows, int cols, int nnz, int iters,
+                     const smvp_run_opts_t *opts, double *y, double *time_each_ms,
+                     smvp_time_stats_t *stats);
+/* Replaces  double *smvp_tjds_compute(MMRawData*, int rows, int cols, int nnz,
+ *                                     int iters, struct _time_data_*)  main-cli.c:734-1162 */
+int smvp_tjds_compute(const smvp_coo_t *coo, int rows, int cols, int nnz, int iters,
+                      const smvp_run_opts_t *opts, double *y, double *time_each_ms,
+                      smvp_time_stats_t *stats);
+
+/* ------------------------------------------------------------ stats + report */
+/* Replaces the reduction at main-cli.c:428-456 and calcStDevDouble (:114-130;
+ * population standard deviation -- the reference's reads uninitialised locals). */
+int smvp_time_stats(const double *time_each_ms, int iters, smvp_time_stats_t *out);
+/* Replaces generateReportText, main-cli.c:246-320: writes
+ * <report_dir>/smvp-toolbox_report_<alg_name>_<unix_time>.txt (opened "a+") with
+ * the reference's exact text.  report_dir NULL or "" = current directory;
+ * unix_time 0 = time(NULL).  The path written is returned in out_path if given. */
+int smvp_generate_report_text(const char *input_file_name, const char *report_dir,
+                              const char *alg_name, int nnz, int rows, int iters,
+                              const double *y, const smvp_time_stats_t *stats,
+                              unsigned long unix_time, char *out_path, size_t out_path_cap);
+
+/* ------------------------------------------------------ synthetic workloads */
+/* SURVEY 8(d) / BASELINE.json configs: matrices generated straight into CSR,
+ * a pure function of (kind, seed, global row) so any row block can be produced
+ * independently (row-block sharding needs no communication). */
+enum {
+    SMVP_SYNTH_MEMPLUS_SHAPED = 1, /* memplus's row-length histogram + band structure, scaled */
+    SMVP_SYNTH_UNIFORM = 2         /* `param` nnz per row, uniform distinct columns */
+};
+/* Row lengths for global rows [row_begin, row_end): lens[row_end-row_begin]. */
+int smvp_synth_row_lengths(int kind, uint64_t seed, int64_t rows_total, int64_t cols_total,
+                           int param, int64_t row_begin, int64_t row_end, int *lens);
+/* Fill col_ind/val for the block given its (local, 0-based) row_ptr; columns
+ * sorted ascending and distinct inside a row; values uniform in [-1, 1). */
+int smvp_synth_fill(int kind, uint64_t seed, int64_t rows_total, int64_t cols_total,
+                    int param, int64_t row_begin, int64_t row_end, const int *row_ptr,
+                    int *col_ind, double *val, int threads);
+/* Row-block partition balanced by nnz: bounds[parts+1], bounds[0]=0, bounds[parts]=rows. */
+int smvp_partition_rows(const int *row_ptr, int rows, int parts, int *bounds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMVP_AMD_H */

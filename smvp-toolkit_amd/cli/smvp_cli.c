@@ -1,0 +1,330 @@
+/*
+ * smvp_cli.c -- smvp-toolkit-cli on the MI355X engine (C host code over the
+ * C ABI in include/smvp_amd.h).
+ *
+ * Keeps the command-line surface of the reference's main() (main-cli.c:1219-1481):
+ *   -a/--all-algs  -c/--csr  -t/--tjds  -g/--cisr-gen  -n/--number INT
+ *   -s/--slots INT  -d/--dir DIR  -?/--help  --usage      <file>
+ * options before the single positional file (POPT_CONTEXT_POSIXMEHARDER,
+ * main-cli.c:1254), the same tagged stdout lines, the same error texts and exit
+ * codes, and the same report file per algorithm (main-cli.c:246-320).
+ *
+ * Deliberate differences, all called out in DESIGN.md:
+ *   - --all-algs runs CSR then TJDS.  In v0.6.4 ALG_ALL (256) shares no bit with
+ *     ALG_CSR / ALG_TJDS, so the reference runs nothing (main-cli.c:34-38,1453).
+ *   - without -d the report goes to the current directory (the reference reads
+ *     an uninitialised pointer, main-cli.c:1223,1458).
+ *   - TJDS is the corrected product unless --ref-quirks is given.
+ *   - -g / -s (CISR .coe generation for an FPGA, main-cli.c:473-729) are
+ *     recognised and refused: out of scope for the GPU engine.
+ *   - libpopt is not used (absent from the image): getopt_long("+...") gives the
+ *     same POSIX ordering rule.
+ * Additive flags: --device N, --ref-quirks, --csr-kernel auto|vector|stream,
+ * --quiet-arrays is implied (the reference's SMVP_CSR_DEBUG array dumps,
+ * main-cli.c:374-394, are not printed).
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "smvp_amd.h"
+
+#include <errno.h>
+#include <getopt.h>
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+
+#define RED "\x1b[31m"
+#define GREEN "\x1b[32m"
+#define YELLOW "\x1b[33m"
+#define MAGENTA "\x1b[35m"
+#define CYAN "\x1b[36m"
+#define RESET "\x1b[0m"
+
+enum { ALG_NONE = 0, ALG_CSR = 1 << 1, ALG_TJDS = 1 << 2, ALG_CISR = 1 << 3, ALG_ALL = 256 };
+enum { OPT_DEVICE = 1000, OPT_QUIRKS, OPT_KERNEL, OPT_USAGE };
+
+static void usage(FILE *to, const char *prog)
+{
+    fprintf(to,
+            "Usage: %s [-acgt?] [-a|--all-algs] [-c|--csr] [-g|--cisr-gen] [-t|--tjds]\n"
+            "        [-n|--number=1000] [-s|--slots=16] [-d|--dir=./] [--device=0]\n"
+            "        [--ref-quirks] [--csr-kernel=auto|vector|stream] [-?|--help] [--usage]\n"
+            "        [OPTIONS] <file>\n",
+            prog);
+}
+
+static void help(const char *prog)
+{
+    printf("Usage: %s [OPTIONS] <file>\n", prog);
+    puts("  -a, --all-algs           Enable all SMVP algorithms.");
+    puts("  -c, --csr                Enable CSR SMVP algorithm.");
+    puts("  -g, --cisr-gen           Generate CISR COE file.");
+    puts("  -t, --tjds               Enable TJDS SMVP algorithm.");
+    puts("  -n, --number=1000        Number of computation iterations per-algorithm.");
+    puts("  -s, --slots=16           Number of slots for CISR.");
+    puts("  -d, --dir=./             Output folder for reports.");
+    puts("      --device=0           HIP device ordinal.");
+    puts("      --ref-quirks         Reproduce the reference v0.6.4 TJDS output, defects included.");
+    puts("      --csr-kernel=auto    CSR kernel family: auto, vector, stream.");
+    puts("\nHelp options:");
+    puts("  -?, --help               Show this help message");
+    puts("      --usage              Display brief usage message");
+}
+
+static void die(const char *msg)
+{
+    printf(RED "[ERROR]\t%s\n" RESET, msg);
+    exit(1);
+}
+
+static int is_dir(const char *path)
+{
+    struct stat st;
+    return stat(path, &st) == 0 && S_ISDIR(st.st_mode);
+}
+
+/* popt's POPT_ARG_INT: the whole argument must be a decimal number */
+static int parse_int(const char *s, int *out)
+{
+    char *end = NULL;
+    errno = 0;
+    long v = strtol(s, &end, 0);
+    if (end == s || *end != '\0')
+        return 1; /* POPT_ERROR_BADNUMBER */
+    if (errno == ERANGE || v > INT_MAX || v < INT_MIN)
+        return 2; /* POPT_ERROR_OVERFLOW */
+    *out = (int)v;
+    return 0;
+}
+
+static void mmio_fail(int rc)
+{
+    /* texts of mmioErrorHandler, main-cli.c:144-166 */
+    if (rc == SMVP_MM_PREMATURE_EOF)
+        die("Could not process specified Matrix Market input file. Required parameters not present on first line of file.");
+    if (rc == SMVP_MM_NO_HEADER)
+        die("Could not process specified Matrix Market input file. Required header is missing or file contents may not be Matrix Market formatted.");
+    if (rc == SMVP_MM_UNSUPPORTED_TYPE)
+        die("Could not process specified Matrix Market input file. Matrix content description not parseable or is absent.");
+    die("Could not process specified Matrix Market input file. Unhandled exception occured during file loading .");
+}
+
+static void engine_fail(const char *what, int rc)
+{
+    printf(RED "[ERROR]\t%s failed (status %d): %s\n" RESET, what, rc, smvp_last_error());
+    exit(1);
+}
+
+static void print_rates(const char *alg, int rows, int cols, int nnz, int diags, const smvp_time_stats_t *t)
+{
+    /* 2*nnz flops; 12*nnz + 4*(rows+1 | diags+1) + 8*cols + 8*rows bytes */
+    const double flops = 2.0 * nnz;
+    const double bytes = 12.0 * nnz + 4.0 * ((diags >= 0 ? diags : rows) + 1.0) + 8.0 * cols + 8.0 * rows;
+    if (t->time_avg > 0.0)
+        printf(CYAN "[DATA]\t%s average per product: " RESET "%g ms, %.3f GFLOP/s, %.3f GB/s algorithmic\n", alg,
+               t->time_avg, flops / t->time_avg * 1e-6, bytes / t->time_avg * 1e-6);
+}
+
+int main(int argc, char *argv[])
+{
+    static const struct option longopts[] = {
+        {"all-algs", no_argument, NULL, 'a'},      {"csr", no_argument, NULL, 'c'},
+        {"cisr-gen", no_argument, NULL, 'g'},      {"tjds", no_argument, NULL, 't'},
+        {"number", required_argument, NULL, 'n'},  {"slots", required_argument, NULL, 's'},
+        {"dir", required_argument, NULL, 'd'},     {"help", no_argument, NULL, '?'},
+        {"usage", no_argument, NULL, OPT_USAGE},   {"device", required_argument, NULL, OPT_DEVICE},
+        {"ref-quirks", no_argument, NULL, OPT_QUIRKS}, {"csr-kernel", required_argument, NULL, OPT_KERNEL},
+        {NULL, 0, NULL, 0}};
+    const char *prog = "smvp-toolkit-cli";
+    int alg_mode = ALG_NONE, calc_iter = 1000, cisr_slots = 16, device = 0, quirks = 0;
+    int csr_kernel = SMVP_CSR_KERNEL_AUTO;
+    const char *report_dir = "";
+
+    if (argc < 2) { /* main-cli.c:1267-1271 */
+        usage(stderr, prog);
+        return 1;
+    }
+
+    opterr = 0;
+    int c, v;
+    while ((c = getopt_long(argc, argv, "+:acgtn:s:d:?", longopts, NULL)) != -1) {
+        switch (c) {
+        case 'a':
+            if (alg_mode != ALG_NONE)
+                die("Combining [-a|--all] with other algorithm flags is not supported.");
+            alg_mode = ALG_ALL;
+            break;
+        case 'c':
+        case 't':
+        case 'g':
+            if (alg_mode == ALG_ALL)
+                die("Combining [-a|--all] with other algorithm flags is not supported.");
+            alg_mode |= (c == 'c') ? ALG_CSR : (c == 't') ? ALG_TJDS : ALG_CISR;
+            break;
+        case 'n':
+        case 's':
+            switch (parse_int(optarg, &v)) {
+            case 1:
+                die("Argument for iteration count contains non-number characters.");
+                break;
+            case 2:
+                die("Argument for iteration count must be between 0 and approximately 1.8E19 (64-bit integer).");
+                break;
+            default:
+                break;
+            }
+            if (v < 1)
+                die(c == 'n' ? "Invalid number of algorithm iterations specified."
+                             : "Invalid number of CISR slots specified.");
+            if (c == 'n')
+                calc_iter = v;
+            else
+                cisr_slots = v;
+            break;
+        case 'd':
+            if (!is_dir(optarg))
+                die("Report output folder not found. Check path and/or create folder if it does not exist.");
+            report_dir = optarg;
+            break;
+        case OPT_DEVICE:
+            if (parse_int(optarg, &v) != 0 || v < 0)
+                die("Invalid device ordinal specified.");
+            device = v;
+            break;
+        case OPT_QUIRKS:
+            quirks = 1;
+            break;
+        case OPT_KERNEL:
+            if (strcmp(optarg, "auto") == 0)
+                csr_kernel = SMVP_CSR_KERNEL_AUTO;
+            else if (strcmp(optarg, "vector") == 0)
+                csr_kernel = SMVP_CSR_KERNEL_VECTOR;
+            else if (strcmp(optarg, "stream") == 0)
+                csr_kernel = SMVP_CSR_KERNEL_STREAM;
+            else
+                die("Unknown CSR kernel family (use auto, vector or stream).");
+            break;
+        case OPT_USAGE:
+            usage(stdout, prog);
+            return 0;
+        case ':':
+            die("One or more options missing a required argument.");
+            break;
+        case '?':
+        default:
+            if (optopt == 0 || optopt == '?') { /* a literal -? / --help, or an unknown long option */
+                if (optind > 0 && optind <= argc && argv[optind - 1] &&
+                    (strcmp(argv[optind - 1], "-?") == 0 || strcmp(argv[optind - 1], "--help") == 0)) {
+                    help(prog);
+                    return 0;
+                }
+                fprintf(stderr, "%s: unknown option\n", argv[optind - 1] ? argv[optind - 1] : "?");
+            } else {
+                fprintf(stderr, "-%c: unknown option\n", optopt);
+            }
+            return 1;
+        }
+    }
+    (void)cisr_slots;
+
+    /* exactly one positional argument, main-cli.c:1389-1393 */
+    if (optind != argc - 1) {
+        usage(stderr, prog);
+        fprintf(stderr, "%s: %s", RED "[ERROR]\tMust specify a single input file", "ex., /path/to/file.mtx\n" RESET);
+        return 1;
+    }
+    const char *input = argv[optind];
+    FILE *f = fopen(input, "r");
+    if (!f)
+        die("Specified input file not found.");
+
+    printf(GREEN "\n[START]\tExecuting smvp-toolbox-cli v%s\n" RESET, smvp_version_string());
+
+    smvp_mm_typecode tc;
+    int rc = smvp_mm_read_banner(f, &tc);
+    if (rc != SMVP_OK)
+        mmio_fail(rc);
+    if (tc[1] != 'C')
+        die("This application only supports sparse matricies. Specified input file does not appear to contain a sparse matrix.");
+
+    printf(MAGENTA "[FILE]\tInput matrix file name: " RESET "%s\n", input);
+    printf(YELLOW "[INFO]\tLoading matrix content from source file.\n" RESET);
+    int rows = 0, cols = 0, nnz = 0;
+    rc = smvp_mm_read_mtx_crd_size(f, &rows, &cols, &nnz);
+    if (rc != SMVP_OK)
+        mmio_fail(rc);
+    if (rows < 0 || cols < 0 || nnz < 0)
+        mmio_fail(SMVP_MM_UNSUPPORTED_TYPE);
+
+    smvp_coo_t *coo = malloc(sizeof *coo * (size_t)(nnz > 0 ? nnz : 1)); /* heap, not a stack VLA (main-cli.c:1426) */
+    double *y = malloc(sizeof *y * (size_t)(rows > 0 ? rows : 1));
+    double *each = malloc(sizeof *each * (size_t)calc_iter);
+    if (!coo || !y || !each)
+        die("Out of memory while staging the matrix.");
+    rc = smvp_mm_read_coo_entries(f, tc, nnz, coo);
+    if (rc != SMVP_OK)
+        mmio_fail(rc);
+    if (f != stdin)
+        fclose(f);
+
+    printf(CYAN "[DATA]\tNon-zero numbers contained in matrix: " RESET "%d\n", nnz);
+    printf(CYAN "[DATA]\tVector operand in use: " RESET "Ones vector with dimensions [%d, %d]\n", rows, 1);
+
+    if (alg_mode & ALG_CISR)
+        die("CISR COE generation targets an FPGA flow and is not part of the MI355X engine.");
+
+    const int run_csr = (alg_mode == ALG_ALL) || (alg_mode & ALG_CSR);
+    const int run_tjds = (alg_mode == ALG_ALL) || (alg_mode & ALG_TJDS);
+    if (run_csr || run_tjds) {
+        char name[256];
+        int cus = 0;
+        size_t mem = 0;
+        rc = smvp_device_info(device, name, sizeof name, &cus, &mem);
+        if (rc != SMVP_OK)
+            engine_fail("Selecting the GPU", rc);
+        printf(CYAN "[DATA]\tCompute device %d: " RESET "%s, %d CUs, %.0f GiB\n", device, name, cus,
+               (double)mem / (1024.0 * 1024.0 * 1024.0));
+    }
+
+    smvp_run_opts_t opts;
+    smvp_run_opts_default(&opts);
+    opts.device = device;
+    opts.csr_kernel = csr_kernel;
+    opts.tjds_ref_quirks = quirks;
+    smvp_time_stats_t st;
+    char path[4096];
+
+    if (run_csr) {
+        printf(YELLOW "[INFO]\tConverting loaded content to CSR format.\n" RESET);
+        printf(YELLOW "[INFO]\tCalculating %d iterations of SMVP CSR.\n" RESET, calc_iter);
+        rc = smvp_csr_compute(coo, rows, cols, nnz, calc_iter, &opts, y, each, &st);
+        if (rc != SMVP_OK)
+            engine_fail("CSR product", rc);
+        rc = smvp_generate_report_text(input, report_dir, "CSR", nnz, rows, calc_iter, y, &st, 0, path, sizeof path);
+        if (rc != SMVP_OK)
+            engine_fail("Writing the CSR report", rc);
+        printf(MAGENTA "[FILE]\tExecution report file saved as:\n" RESET);
+        printf("\t%s\n", path);
+        print_rates("CSR", rows, cols, nnz, -1, &st);
+    }
+    if (run_tjds) {
+        printf(YELLOW "[INFO]\tConverting loaded content to TJDS format.\n" RESET);
+        printf(YELLOW "[INFO]\tCalculating %d iterations of SMVP TJDS.\n" RESET, calc_iter);
+        rc = smvp_tjds_compute(coo, rows, cols, nnz, calc_iter, &opts, y, each, &st);
+        if (rc != SMVP_OK)
+            engine_fail("TJDS product", rc);
+        rc = smvp_generate_report_text(input, report_dir, "TJDS", nnz, rows, calc_iter, y, &st, 0, path, sizeof path);
+        if (rc != SMVP_OK)
+            engine_fail("Writing the TJDS report", rc);
+        printf(MAGENTA "[FILE]\tExecution report file saved as:\n" RESET);
+        printf("\t%s\n", path);
+        print_rates("TJDS", rows, cols, nnz, 0, &st);
+    }
+
+    free(each);
+    free(y);
+    free(coo);
+    printf(GREEN "[STOP]\tExit smvp-toolbox v%s\n\n" RESET, smvp_version_string());
+    return 0;
+}

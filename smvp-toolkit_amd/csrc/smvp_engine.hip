@@ -1,0 +1,703 @@
+// smvp_engine.hip -- device-resident matrices, launch plans and the two
+// reference-shaped compute entry points.
+//
+//   smvp_csr_compute   replaces main-cli.c:325-469
+//   smvp_tjds_compute  replaces main-cli.c:734-1162
+// The conversion halves live in smvp_convert.cpp (host); this file owns what
+// the reference keeps in CSRData / TJDSData (main-cli.c:61-75) once it is in
+// HBM, the per-matrix launch plan, and the timed iteration loop
+// (main-cli.c:402-420, :1004-1024) with hipEvents in place of clock_gettime.
+#include "smvp_common.h"
+#include "smvp_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return smvp::fail(SMVP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+
+int usable_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return smvp::fail(SMVP_ERR_NO_DEVICE, "no HIP device is visible (this engine has no CPU path)");
+    if (device < 0 || device >= n)
+        return smvp::fail(SMVP_ERR_INVALID, "device %d out of range (%d visible)", device, n);
+    return SMVP_OK;
+}
+
+template <class T>
+int to_device(T **dst, const T *src, size_t count, int mem_kind, bool *owned)
+{
+    if (mem_kind == SMVP_MEM_DEVICE) {
+        *dst = const_cast<T *>(src);
+        *owned = false;
+        return SMVP_OK;
+    }
+    *owned = true;
+    HIP_TRY(hipMalloc((void **)dst, std::max<size_t>(count, 4) * sizeof(T)));
+    if (count)
+        HIP_TRY(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return SMVP_OK;
+}
+
+template <class T>
+int upload(T **dst, const std::vector<T> &src)
+{
+    HIP_TRY(hipMalloc((void **)dst, std::max<size_t>(src.size(), 4) * sizeof(T)));
+    if (!src.empty())
+        HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SMVP_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// CSR
+// ===========================================================================
+struct smvp_csr {
+    int device = 0;
+    int rows = 0, cols = 0, nnz = 0;
+    int *d_row_ptr = nullptr;
+    int *d_col_ind = nullptr;
+    double *d_val = nullptr;
+    bool own_row_ptr = false, own_col_ind = false, own_val = false;
+    std::vector<int> h_row_ptr;  // kept for re-planning
+
+    int kernel = SMVP_CSR_KERNEL_AUTO;  // resolved: VECTOR or STREAM
+    int lanes_per_row = 64;             // VECTOR
+    int vpt = 4;                        // STREAM: entries per thread (tile = 256 * vpt)
+    int ntiles = 0;
+    int *d_tile_row = nullptr;
+    int *d_carry_row = nullptr;
+    double *d_carry = nullptr;
+};
+
+namespace {
+
+void free_stream_plan(smvp_csr *h)
+{
+    if (h->d_tile_row)
+        (void)hipFree(h->d_tile_row);
+    if (h->d_carry_row)
+        (void)hipFree(h->d_carry_row);
+    if (h->d_carry)
+        (void)hipFree(h->d_carry);
+    h->d_tile_row = h->d_carry_row = nullptr;
+    h->d_carry = nullptr;
+    h->ntiles = 0;
+}
+
+// tile_row[b]  = first row whose first entry lies at or after b*TILE
+// carry_row[b] = row that the entries in front of that row belong to, or -1
+int build_stream_plan(smvp_csr *h)
+{
+    free_stream_plan(h);
+    const int tile = smvp::kStreamBlock * h->vpt;
+    const long long nnz = h->nnz;
+    const int ntiles = (int)std::max<long long>(1, (nnz + tile - 1) / tile);
+    std::vector<int> tile_row((size_t)ntiles + 1), carry_row((size_t)ntiles);
+    const int *rp = h->h_row_ptr.data();
+    int r = 0;
+    for (int b = 0; b < ntiles; ++b) {
+        const long long s = (long long)b * tile;
+        const long long e = std::min(s + tile, nnz);
+        while (r < h->rows && rp[r] < s)
+            ++r;
+        tile_row[(size_t)b] = r;
+        const long long first = r < h->rows ? rp[r] : nnz;
+        carry_row[(size_t)b] = (std::min(first, e) > s) ? r - 1 : -1;
+    }
+    tile_row[(size_t)ntiles] = h->rows;
+    if (int rc = upload(&h->d_tile_row, tile_row))
+        return rc;
+    if (int rc = upload(&h->d_carry_row, carry_row))
+        return rc;
+    HIP_TRY(hipMalloc((void **)&h->d_carry, std::max(ntiles, 1) * sizeof(double)));
+    HIP_TRY(hipMemset(h->d_carry, 0, std::max(ntiles, 1) * sizeof(double)));
+    h->ntiles = ntiles;
+    return SMVP_OK;
+}
+
+int pow2_at_least(double v)
+{
+    int p = 2;
+    while (p < 64 && p < v)
+        p <<= 1;
+    return p;
+}
+
+// AUTO: fixed-nnz tiles are insensitive to row-length skew and keep short rows
+// at full lane use, so they are the default; very long uniform rows go to the
+// wavefront-per-row kernel.
+void choose_csr_kernel(smvp_csr *h, int kernel, int param)
+{
+    const double mean = h->rows > 0 ? (double)h->nnz / h->rows : 0.0;
+    if (kernel == SMVP_CSR_KERNEL_AUTO)
+        kernel = mean >= 96.0 ? SMVP_CSR_KERNEL_VECTOR : SMVP_CSR_KERNEL_STREAM;
+    h->kernel = kernel;
+    if (kernel == SMVP_CSR_KERNEL_VECTOR) {
+        h->lanes_per_row = param > 0 ? param : pow2_at_least(mean);
+    } else {
+        int tile = param > 0 ? param : 0;
+        if (tile == 0) {
+            // enough tiles to cover the chip a few times over, else the small tile
+            const long long want_tiles = 256 * 8;
+            tile = (h->nnz / 2048 >= want_tiles) ? 2048 : 1024;
+        }
+        h->vpt = tile / smvp::kStreamBlock;
+    }
+}
+
+}  // namespace
+
+extern "C" int smvp_csr_create(smvp_csr_t **out, int device, int rows, int cols, int nnz,
+                               const int *row_ptr, const int *col_ind, const double *val,
+                               int mem_kind, const int *host_row_ptr)
+{
+    if (!out || rows < 0 || cols < 0 || nnz < 0 || !row_ptr || (nnz > 0 && (!col_ind || !val)))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: bad argument");
+    if (mem_kind != SMVP_MEM_HOST && mem_kind != SMVP_MEM_DEVICE)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: bad mem_kind");
+    if (int rc = usable_device(device))
+        return rc;
+    HIP_TRY(hipSetDevice(device));
+
+    smvp_csr *h = new smvp_csr;
+    h->device = device;
+    h->rows = rows, h->cols = cols, h->nnz = nnz;
+    h->h_row_ptr.resize((size_t)rows + 1);
+    int rc = SMVP_OK;
+    if (mem_kind == SMVP_MEM_HOST || host_row_ptr) {
+        memcpy(h->h_row_ptr.data(), mem_kind == SMVP_MEM_HOST ? row_ptr : host_row_ptr, sizeof(int) * ((size_t)rows + 1));
+    } else if (hipMemcpy(h->h_row_ptr.data(), row_ptr, sizeof(int) * ((size_t)rows + 1), hipMemcpyDeviceToHost) != hipSuccess) {
+        rc = smvp::fail(SMVP_ERR_HIP, "smvp_csr_create: cannot read row_ptr back from the device");
+    }
+    // The kernels index with these; a malformed row_ptr would read out of bounds.
+    if (rc == SMVP_OK) {
+        const std::vector<int> &rp = h->h_row_ptr;
+        bool ok = rp[0] == 0 && rp[(size_t)rows] == nnz;
+        for (int r = 0; r < rows && ok; ++r)
+            ok = rp[(size_t)r] <= rp[(size_t)r + 1];
+        if (!ok)
+            rc = smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: row_ptr is not a non-decreasing 0..nnz sequence");
+    }
+    if (rc == SMVP_OK && mem_kind == SMVP_MEM_HOST) {
+        for (int j = 0; j < nnz; ++j)
+            if (col_ind[j] < 0 || col_ind[j] >= cols) {
+                rc = smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: col_ind[%d] = %d outside [0, %d)", j, col_ind[j], cols);
+                break;
+            }
+    }
+    if (rc == SMVP_OK && mem_kind == SMVP_MEM_DEVICE &&
+        (((uintptr_t)col_ind | (uintptr_t)val) & 15u) != 0)
+        rc = smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: adopted device arrays must be 16-byte aligned");
+    if (rc == SMVP_OK)
+        rc = to_device(&h->d_row_ptr, row_ptr, (size_t)rows + 1, mem_kind, &h->own_row_ptr);
+    if (rc == SMVP_OK)
+        rc = to_device(&h->d_col_ind, col_ind, (size_t)nnz, mem_kind, &h->own_col_ind);
+    if (rc == SMVP_OK)
+        rc = to_device(&h->d_val, val, (size_t)nnz, mem_kind, &h->own_val);
+    if (rc == SMVP_OK) {
+        choose_csr_kernel(h, SMVP_CSR_KERNEL_AUTO, 0);
+        if (h->kernel == SMVP_CSR_KERNEL_STREAM)
+            rc = build_stream_plan(h);
+    }
+    if (rc != SMVP_OK) {
+        smvp_csr_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return SMVP_OK;
+}
+
+extern "C" int smvp_csr_set_kernel(smvp_csr_t *h, int kernel, int param)
+{
+    if (!h)
+        return smvp::fail(SMVP_ERR_INVALID, "null handle");
+    if (kernel < SMVP_CSR_KERNEL_AUTO || kernel > SMVP_CSR_KERNEL_STREAM)
+        return smvp::fail(SMVP_ERR_INVALID, "unknown CSR kernel %d", kernel);
+    if (kernel == SMVP_CSR_KERNEL_VECTOR && param != 0 &&
+        (param < 2 || param > 64 || (param & (param - 1)) != 0))
+        return smvp::fail(SMVP_ERR_INVALID, "lanes per row must be a power of two in [2, 64]");
+    if (kernel == SMVP_CSR_KERNEL_STREAM && param != 0 && param != 1024 && param != 2048)
+        return smvp::fail(SMVP_ERR_INVALID, "entries per tile must be 1024 or 2048");
+    HIP_TRY(hipSetDevice(h->device));
+    choose_csr_kernel(h, kernel, param);
+    if (h->kernel == SMVP_CSR_KERNEL_STREAM)
+        return build_stream_plan(h);
+    free_stream_plan(h);
+    return SMVP_OK;
+}
+
+extern "C" int smvp_csr_get_kernel(const smvp_csr_t *h, int *kernel, int *param)
+{
+    if (!h)
+        return smvp::fail(SMVP_ERR_INVALID, "null handle");
+    if (kernel)
+        *kernel = h->kernel;
+    if (param)
+        *param = h->kernel == SMVP_CSR_KERNEL_VECTOR ? h->lanes_per_row : h->vpt * smvp::kStreamBlock;
+    return SMVP_OK;
+}
+
+extern "C" int smvp_csr_spmv(smvp_csr_t *h, const double *d_x, double *d_y, void *stream)
+{
+    if (!h || (h->rows > 0 && !d_y) || (h->nnz > 0 && !d_x))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_spmv: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+    if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
+        e = smvp::launch_csr_vector(h->lanes_per_row, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y, h->rows, st);
+    else
+        e = smvp::launch_csr_stream(h->vpt, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y, h->d_tile_row,
+                                    h->d_carry_row, h->d_carry, h->rows, h->nnz, h->ntiles, st);
+    if (e != hipSuccess)
+        return smvp::fail(SMVP_ERR_HIP, "CSR launch failed: %s", hipGetErrorString(e));
+    return SMVP_OK;
+}
+
+extern "C" int smvp_csr_describe(const smvp_csr_t *h, char *kernel_name, size_t cap, double *alg_bytes)
+{
+    if (!h)
+        return smvp::fail(SMVP_ERR_INVALID, "null handle");
+    if (kernel_name && cap) {
+        if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
+            snprintf(kernel_name, cap, "csr_vector_rows<%d>", h->lanes_per_row);
+        else
+            snprintf(kernel_name, cap, "csr_stream_tiles<%d>", h->vpt);
+    }
+    if (alg_bytes)
+        *alg_bytes = 12.0 * h->nnz + 4.0 * (h->rows + 1.0) + 8.0 * h->cols + 8.0 * h->rows;
+    return SMVP_OK;
+}
+
+extern "C" void smvp_csr_destroy(smvp_csr_t *h)
+{
+    if (!h)
+        return;
+    (void)hipSetDevice(h->device);
+    free_stream_plan(h);
+    if (h->own_row_ptr && h->d_row_ptr)
+        (void)hipFree(h->d_row_ptr);
+    if (h->own_col_ind && h->d_col_ind)
+        (void)hipFree(h->d_col_ind);
+    if (h->own_val && h->d_val)
+        (void)hipFree(h->d_val);
+    delete h;
+}
+
+// ===========================================================================
+// TJDS
+// ===========================================================================
+struct smvp_tjds {
+    int device = 0;
+    int rows = 0, cols = 0, nnz = 0, num_diag = 0;
+    int *d_perm = nullptr;
+    int *d_start_pos = nullptr;  // num_diag + 1 entries (+1 pad)
+    int *d_row_ind = nullptr;
+    double *d_val = nullptr;
+    bool own_perm = false, own_start_pos = false, own_row_ind = false, own_val = false;
+    std::vector<int> h_start_pos;
+
+    double *d_x_perm = nullptr;  // max(rows, cols) doubles
+    bool x_set = false;
+
+    // launch plan (rebuilt when ref-quirks mode changes)
+    bool quirks = false;
+    int *d_plan_start_pos = nullptr;  // start_pos as the kernel should see it
+    int4 *d_work = nullptr;
+    int nwork = 0;
+    long long planned_nnz = 0;
+};
+
+namespace {
+
+int build_tjds_plan(smvp_tjds *h, bool quirks, int ref_num_tjdiag, int last_diag_single)
+{
+    if (h->d_plan_start_pos)
+        (void)hipFree(h->d_plan_start_pos);
+    if (h->d_work)
+        (void)hipFree(h->d_work);
+    h->d_plan_start_pos = nullptr;
+    h->d_work = nullptr;
+
+    // start_pos as the product loop sees it, plus two readable pads
+    std::vector<int> sp((size_t)h->num_diag + 3, 0);
+    for (int d = 0; d <= h->num_diag; ++d)
+        sp[(size_t)d] = h->h_start_pos[(size_t)d];
+    int diag_limit = h->num_diag;
+    if (quirks) {
+        // main-cli.c:865 + :1013: diagonals 0 .. ref_num_tjdiag inclusive;
+        // main-cli.c:951-966: terminator never written after a one-entry last
+        // diagonal, and the malloc'd array reads as zero there.
+        if (last_diag_single)
+            sp[(size_t)h->num_diag] = 0;
+        diag_limit = std::min(h->num_diag, ref_num_tjdiag + 1);
+    }
+    std::vector<int4> work;
+    long long planned = 0;
+    for (int d0 = 0; d0 < diag_limit; d0 += smvp::kTjdsDiagChunk) {
+        const int d1 = std::min(d0 + smvp::kTjdsDiagChunk, diag_limit);
+        const int width = sp[(size_t)d0 + 1] - sp[(size_t)d0];  // widest diagonal of the chunk
+        for (int k0 = 0; k0 < width; k0 += smvp::kTjdsBlock)
+            work.push_back(make_int4(k0, d0, d1, 0));
+        for (int d = d0; d < d1; ++d)
+            planned += std::max(0, sp[(size_t)d + 1] - sp[(size_t)d]);
+    }
+    if (int rc = upload(&h->d_plan_start_pos, sp))
+        return rc;
+    if (int rc = upload(&h->d_work, work))
+        return rc;
+    h->nwork = (int)work.size();
+    h->quirks = quirks;
+    h->planned_nnz = planned;
+    return SMVP_OK;
+}
+
+}  // namespace
+
+extern "C" int smvp_tjds_create(smvp_tjds_t **out, int device, int rows, int cols, int nnz, int num_diag,
+                                const int *perm, const int *start_pos, const int *row_ind,
+                                const double *val, int mem_kind)
+{
+    if (!out || rows < 0 || cols < 0 || nnz < 0 || num_diag < 0 || !start_pos || (cols > 0 && !perm) ||
+        (nnz > 0 && (!row_ind || !val)))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_create: bad argument");
+    if (mem_kind != SMVP_MEM_HOST && mem_kind != SMVP_MEM_DEVICE)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_create: bad mem_kind");
+    if (int rc = usable_device(device))
+        return rc;
+    HIP_TRY(hipSetDevice(device));
+
+    smvp_tjds *h = new smvp_tjds;
+    h->device = device;
+    h->rows = rows, h->cols = cols, h->nnz = nnz, h->num_diag = num_diag;
+    h->h_start_pos.resize((size_t)num_diag + 1);
+    int rc = SMVP_OK;
+    if (mem_kind == SMVP_MEM_HOST)
+        memcpy(h->h_start_pos.data(), start_pos, sizeof(int) * ((size_t)num_diag + 1));
+    else if (hipMemcpy(h->h_start_pos.data(), start_pos, sizeof(int) * ((size_t)num_diag + 1), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = smvp::fail(SMVP_ERR_HIP, "smvp_tjds_create: cannot read start_pos back from the device");
+    if (rc == SMVP_OK) {
+        // diagonals start at 0, end at nnz, and never get longer; the first one
+        // has at most `cols` entries -- the kernel's indexing relies on all of it
+        const std::vector<int> &sp = h->h_start_pos;
+        bool ok = sp[0] == 0 && sp[(size_t)num_diag] == nnz;
+        int prev = cols;
+        for (int d = 0; d < num_diag && ok; ++d) {
+            const int len = sp[(size_t)d + 1] - sp[(size_t)d];
+            ok = len >= 1 && len <= prev;
+            prev = len;
+        }
+        if (!ok)
+            rc = smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_create: start_pos is not a valid jagged-diagonal index");
+    }
+    if (rc == SMVP_OK && mem_kind == SMVP_MEM_HOST) {
+        for (int j = 0; j < nnz && rc == SMVP_OK; ++j)
+            if (row_ind[j] < 0 || row_ind[j] >= rows)
+                rc = smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_create: row_ind[%d] = %d outside [0, %d)", j, row_ind[j], rows);
+        for (int k = 0; k < cols && rc == SMVP_OK; ++k)
+            if (perm[k] < 0 || perm[k] >= cols)
+                rc = smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_create: perm[%d] = %d outside [0, %d)", k, perm[k], cols);
+    }
+    if (rc == SMVP_OK)
+        rc = to_device(&h->d_perm, perm, (size_t)cols, mem_kind, &h->own_perm);
+    if (rc == SMVP_OK)
+        rc = to_device(&h->d_start_pos, start_pos, (size_t)num_diag + 1, mem_kind, &h->own_start_pos);
+    if (rc == SMVP_OK)
+        rc = to_device(&h->d_row_ind, row_ind, (size_t)nnz, mem_kind, &h->own_row_ind);
+    if (rc == SMVP_OK)
+        rc = to_device(&h->d_val, val, (size_t)nnz, mem_kind, &h->own_val);
+    if (rc == SMVP_OK) {
+        const size_t n = (size_t)std::max(std::max(rows, cols), 1);
+        if (hipMalloc((void **)&h->d_x_perm, n * sizeof(double)) != hipSuccess ||
+            hipMemset(h->d_x_perm, 0, n * sizeof(double)) != hipSuccess)
+            rc = smvp::fail(SMVP_ERR_ALLOC, "smvp_tjds_create: cannot allocate the permuted operand");
+    }
+    if (rc == SMVP_OK)
+        rc = build_tjds_plan(h, false, 0, 0);
+    if (rc != SMVP_OK) {
+        smvp_tjds_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return SMVP_OK;
+}
+
+extern "C" int smvp_tjds_set_x(smvp_tjds_t *h, const double *d_x, void *stream)
+{
+    if (!h || (h->cols > 0 && !d_x))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_set_x: bad argument");
+    hipError_t e = smvp::launch_tjds_permute(h->d_perm, d_x, h->d_x_perm, h->cols, (hipStream_t)stream);
+    if (e != hipSuccess)
+        return smvp::fail(SMVP_ERR_HIP, "operand permute launch failed: %s", hipGetErrorString(e));
+    h->x_set = true;
+    return SMVP_OK;
+}
+
+extern "C" int smvp_tjds_zero_y(smvp_tjds_t *h, double *d_y, void *stream)
+{
+    if (!h || (h->rows > 0 && !d_y))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_zero_y: bad argument");
+    if (h->rows > 0)
+        HIP_TRY(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)h->rows, (hipStream_t)stream));
+    return SMVP_OK;
+}
+
+extern "C" int smvp_tjds_spmv(smvp_tjds_t *h, double *d_y, void *stream)
+{
+    if (!h || (h->rows > 0 && !d_y))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_spmv: bad argument");
+    if (!h->x_set)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_spmv: call smvp_tjds_set_x first");
+    if (h->quirks && h->rows != h->cols)
+        return smvp::fail(SMVP_ERR_UNSUPPORTED, "ref-quirks mode indexes the operand by row and needs a square matrix");
+    hipError_t e = smvp::launch_tjds_scatter(h->quirks, h->d_plan_start_pos, h->d_row_ind, h->d_val, h->d_x_perm, d_y,
+                                             h->d_work, h->nwork, h->cols, (hipStream_t)stream);
+    if (e != hipSuccess)
+        return smvp::fail(SMVP_ERR_HIP, "TJDS launch failed: %s", hipGetErrorString(e));
+    return SMVP_OK;
+}
+
+extern "C" int smvp_tjds_set_ref_quirks(smvp_tjds_t *h, int enable, int ref_num_tjdiag, int last_diag_single)
+{
+    if (!h || (enable && ref_num_tjdiag < 0))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_set_ref_quirks: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    return build_tjds_plan(h, enable != 0, ref_num_tjdiag, last_diag_single);
+}
+
+extern "C" int smvp_tjds_describe(const smvp_tjds_t *h, char *kernel_name, size_t cap, double *alg_bytes)
+{
+    if (!h)
+        return smvp::fail(SMVP_ERR_INVALID, "null handle");
+    if (kernel_name && cap)
+        snprintf(kernel_name, cap, "tjds_colmajor_scatter<%s>", h->quirks ? "true" : "false");
+    if (alg_bytes)
+        *alg_bytes = 12.0 * h->planned_nnz + 4.0 * (h->num_diag + 1.0) + 8.0 * h->cols + 8.0 * h->rows;
+    return SMVP_OK;
+}
+
+extern "C" void smvp_tjds_destroy(smvp_tjds_t *h)
+{
+    if (!h)
+        return;
+    (void)hipSetDevice(h->device);
+    if (h->own_perm && h->d_perm)
+        (void)hipFree(h->d_perm);
+    if (h->own_start_pos && h->d_start_pos)
+        (void)hipFree(h->d_start_pos);
+    if (h->own_row_ind && h->d_row_ind)
+        (void)hipFree(h->d_row_ind);
+    if (h->own_val && h->d_val)
+        (void)hipFree(h->d_val);
+    if (h->d_x_perm)
+        (void)hipFree(h->d_x_perm);
+    if (h->d_plan_start_pos)
+        (void)hipFree(h->d_plan_start_pos);
+    if (h->d_work)
+        (void)hipFree(h->d_work);
+    delete h;
+}
+
+// ===========================================================================
+// device queries
+// ===========================================================================
+extern "C" int smvp_device_count(int *count)
+{
+    if (!count)
+        return smvp::fail(SMVP_ERR_INVALID, "null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        n = 0;
+    *count = n;
+    return SMVP_OK;
+}
+
+extern "C" int smvp_device_info(int device, char *name, size_t name_cap, int *compute_units, size_t *hbm_bytes)
+{
+    if (int rc = usable_device(device))
+        return rc;
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    if (name && name_cap)
+        snprintf(name, name_cap, "%s (%s)", p.name, p.gcnArchName);
+    if (compute_units)
+        *compute_units = p.multiProcessorCount;
+    if (hbm_bytes)
+        *hbm_bytes = p.totalGlobalMem;
+    return SMVP_OK;
+}
+
+// ===========================================================================
+// reference-shaped entry points
+// ===========================================================================
+extern "C" void smvp_run_opts_default(smvp_run_opts_t *o)
+{
+    if (!o)
+        return;
+    memset(o, 0, sizeof *o);
+    o->csr_kernel = SMVP_CSR_KERNEL_AUTO;
+}
+
+namespace {
+
+// Scope guard for the scratch the two entry points allocate.
+struct RunScratch {
+    double *d_x = nullptr, *d_y = nullptr;
+    std::vector<hipEvent_t> ev;
+    hipStream_t stream = nullptr;
+    smvp_csr_t *csr = nullptr;
+    smvp_tjds_t *tjds = nullptr;
+    ~RunScratch()
+    {
+        for (hipEvent_t e : ev)
+            (void)hipEventDestroy(e);
+        if (d_x)
+            (void)hipFree(d_x);
+        if (d_y)
+            (void)hipFree(d_y);
+        if (stream)
+            (void)hipStreamDestroy(stream);
+        smvp_csr_destroy(csr);
+        smvp_tjds_destroy(tjds);
+    }
+};
+
+int prepare_run(RunScratch &s, int rows, int cols, int iters, const smvp_run_opts_t *o)
+{
+    HIP_TRY(hipStreamCreate(&s.stream));
+    HIP_TRY(hipMalloc((void **)&s.d_x, sizeof(double) * (size_t)std::max(std::max(cols, rows), 1)));
+    HIP_TRY(hipMalloc((void **)&s.d_y, sizeof(double) * (size_t)std::max(rows, 1)));
+    if (o->x) {
+        HIP_TRY(hipMemcpy(s.d_x, o->x, sizeof(double) * (size_t)cols, hipMemcpyHostToDevice));
+    } else {
+        // vectorInit(rows, onesVector, 1), main-cli.c:368-369 / :761-762
+        hipError_t e = smvp::launch_fill(s.d_x, 1.0, std::max(cols, rows), s.stream);
+        if (e != hipSuccess)
+            return smvp::fail(SMVP_ERR_HIP, "fill launch failed: %s", hipGetErrorString(e));
+    }
+    s.ev.resize((size_t)iters * 2);
+    for (auto &e : s.ev)
+        e = nullptr;
+    for (auto &e : s.ev)
+        HIP_TRY(hipEventCreate(&e));
+    return SMVP_OK;
+}
+
+int finish_run(RunScratch &s, int rows, int iters, double *y, double *time_each_ms, smvp_time_stats_t *stats)
+{
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    std::vector<double> local;
+    if (!time_each_ms) {
+        local.resize((size_t)iters);
+        time_each_ms = local.data();
+    }
+    for (int i = 0; i < iters; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s.ev[(size_t)2 * i], s.ev[(size_t)2 * i + 1]));
+        time_each_ms[i] = (double)ms;
+    }
+    if (stats)
+        smvp_time_stats(time_each_ms, iters, stats);
+    if (rows > 0)
+        HIP_TRY(hipMemcpy(y, s.d_y, sizeof(double) * (size_t)rows, hipMemcpyDeviceToHost));
+    return SMVP_OK;
+}
+
+}  // namespace
+
+extern "C" int smvp_csr_compute(const smvp_coo_t *coo, int rows, int cols, int nnz, int iters,
+                                const smvp_run_opts_t *opts, double *y, double *time_each_ms,
+                                smvp_time_stats_t *stats)
+{
+    smvp_run_opts_t def;
+    smvp_run_opts_default(&def);
+    const smvp_run_opts_t *o = opts ? opts : &def;
+    if (iters < 1 || rows < 0 || cols < 0 || nnz < 0 || (rows > 0 && !y))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_compute: bad argument");
+    if (int rc = usable_device(o->device))
+        return rc;
+    HIP_TRY(hipSetDevice(o->device));
+
+    std::vector<int> row_ptr((size_t)rows + 1), col_ind((size_t)std::max(nnz, 1));
+    std::vector<double> val((size_t)std::max(nnz, 1));
+    if (int rc = smvp_csr_from_coo(coo, rows, nnz, row_ptr.data(), col_ind.data(), val.data()))
+        return rc;
+
+    RunScratch s;
+    if (int rc = smvp_csr_create(&s.csr, o->device, rows, cols, nnz, row_ptr.data(), col_ind.data(), val.data(),
+                                 SMVP_MEM_HOST, nullptr))
+        return rc;
+    if (o->csr_kernel != SMVP_CSR_KERNEL_AUTO || o->csr_param != 0)
+        if (int rc = smvp_csr_set_kernel(s.csr, o->csr_kernel, o->csr_param))
+            return rc;
+    if (int rc = prepare_run(s, rows, cols, iters, o))
+        return rc;
+
+    for (int i = 0; i < iters; ++i) {
+        // the reference clears y before every product, outside its timed window
+        // (main-cli.c:405); the CSR kernels overwrite y, the clear is kept so a
+        // kernel that skipped a row could not hide behind the previous result
+        HIP_TRY(hipMemsetAsync(s.d_y, 0, sizeof(double) * (size_t)std::max(rows, 1), s.stream));
+        HIP_TRY(hipEventRecord(s.ev[(size_t)2 * i], s.stream));
+        if (int rc = smvp_csr_spmv(s.csr, s.d_x, s.d_y, s.stream))
+            return rc;
+        HIP_TRY(hipEventRecord(s.ev[(size_t)2 * i + 1], s.stream));
+    }
+    return finish_run(s, rows, iters, y, time_each_ms, stats);
+}
+
+extern "C" int smvp_tjds_compute(const smvp_coo_t *coo, int rows, int cols, int nnz, int iters,
+                                 const smvp_run_opts_t *opts, double *y, double *time_each_ms,
+                                 smvp_time_stats_t *stats)
+{
+    smvp_run_opts_t def;
+    smvp_run_opts_default(&def);
+    const smvp_run_opts_t *o = opts ? opts : &def;
+    if (iters < 1 || rows < 0 || cols < 0 || nnz < 0 || (rows > 0 && !y))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_compute: bad argument");
+    if (int rc = usable_device(o->device))
+        return rc;
+    HIP_TRY(hipSetDevice(o->device));
+
+    std::vector<int> perm((size_t)std::max(cols, 1)), start_pos((size_t)std::max(rows, nnz) + 2),
+        row_ind((size_t)std::max(nnz, 1));
+    std::vector<double> val((size_t)std::max(nnz, 1));
+    int num_diag = 0, ref_num = 0, last_single = 0;
+    if (int rc = smvp_tjds_from_coo(coo, rows, cols, nnz, perm.data(), start_pos.data(), (int)start_pos.size(),
+                                    row_ind.data(), val.data(), &num_diag, &ref_num, &last_single))
+        return rc;
+
+    RunScratch s;
+    if (int rc = smvp_tjds_create(&s.tjds, o->device, rows, cols, nnz, num_diag, perm.data(), start_pos.data(),
+                                  row_ind.data(), val.data(), SMVP_MEM_HOST))
+        return rc;
+    if (o->tjds_ref_quirks)
+        if (int rc = smvp_tjds_set_ref_quirks(s.tjds, 1, ref_num, last_single))
+            return rc;
+    if (int rc = prepare_run(s, rows, cols, iters, o))
+        return rc;
+    if (int rc = smvp_tjds_set_x(s.tjds, s.d_x, s.stream))  // main-cli.c:907-923, setup
+        return rc;
+
+    for (int i = 0; i < iters; ++i) {
+        if (int rc = smvp_tjds_zero_y(s.tjds, s.d_y, s.stream))  // main-cli.c:1008, outside the window
+            return rc;
+        HIP_TRY(hipEventRecord(s.ev[(size_t)2 * i], s.stream));
+        if (int rc = smvp_tjds_spmv(s.tjds, s.d_y, s.stream))
+            return rc;
+        HIP_TRY(hipEventRecord(s.ev[(size_t)2 * i + 1], s.stream));
+    }
+    return finish_run(s, rows, iters, y, time_each_ms, stats);
+}

@@ -1,0 +1,328 @@
+// smvp_kernels.hip -- the CDNA4 (gfx950) SpMV kernels.
+//
+// These replace the two timed loops of the reference:
+//   CSR   main-cli.c:410-416    for row: for j: y[row] += val[j] * x[col_ind[j]]
+//   TJDS  main-cli.c:1013-1020  for diag: for j: y[row_ind[j]] += val[j] * x_perm[...]
+// Both are HBM-bound streaming + gather/scatter work (2 flop per 12 B), so there
+// is no MFMA here: what matters is that val/col_ind/row_ind are read exactly
+// once with wide coalesced loads, that x is gathered through L2 / Infinity Cache,
+// and that y is written once.
+//
+// Compiled with -ffp-contract=off: a product is rounded before it is added,
+// like the reference's x86-64 build, so every row that is summed left to right
+// by one lane is bit-identical to the serial CPU result.
+#include "smvp_kernels.h"
+
+namespace smvp {
+
+// ---------------------------------------------------------------------------
+// wave64 helpers
+// ---------------------------------------------------------------------------
+template <int WIDTH>
+__device__ __forceinline__ double shfl_down_sum(double v)
+{
+#pragma unroll
+    for (int off = WIDTH / 2; off > 0; off >>= 1)
+        v += __shfl_down(v, off, WIDTH);
+    return v;
+}
+
+// Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Give
+// each XCD one contiguous run of tiles so that the rows it works on -- and the
+// near-diagonal part of x they gather -- stay in that XCD's 4 MiB L2.  Speed
+// only: any placement gives the same result.
+__device__ __forceinline__ int xcd_contiguous_tile(int block, int tiles_per_xcd)
+{
+    return (block & 7) * tiles_per_xcd + (block >> 3);
+}
+
+// ---------------------------------------------------------------------------
+// K1: CSR, one sub-wavefront of T lanes per row, __shfl_down sums.
+// T = 64 is the classic wavefront-per-row kernel; smaller T packs 64/T rows
+// into a wave for short rows.  Lane l of a row reads entries a+l, a+l+T, ...
+// so a wave's loads are contiguous runs of col_ind / val.
+// ---------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(kVectorBlock) void csr_vector_rows(
+    const int *__restrict__ row_ptr, const int *__restrict__ col_ind, const double *__restrict__ val,
+    const double *__restrict__ x, double *__restrict__ y, int rows)
+{
+    const long long gid = (long long)blockIdx.x * kVectorBlock + threadIdx.x;
+    const long long row = gid / T;
+    const int lane = threadIdx.x & (T - 1);
+    int a = 0, z = 0;
+    if (row < rows) {
+        a = row_ptr[row];
+        z = row_ptr[row + 1];
+    }
+    double acc = 0.0;
+    for (int j = a + lane; j < z; j += T)
+        acc += val[j] * x[col_ind[j]];
+    acc = shfl_down_sum<T>(acc);
+    if (lane == 0 && row < rows)
+        y[row] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// K2: CSR, fixed-nnz tiles with an LDS-staged segmented reduction.
+//
+// Tile b owns entries [b*TILE, (b+1)*TILE): every block streams the same number
+// of bytes whatever the row lengths are (memplus: 86 % of rows <= 8 entries,
+// 28 % of entries in rows > 64).  Phase 1 loads col_ind / val with 16-byte
+// per-lane loads, gathers x and parks the products in LDS.  Phase 2 walks the
+// rows that START inside the tile (tile_row[b] .. tile_row[b+1]): one lane per
+// short row sums its segment left to right out of LDS; rows longer than
+// kLongRow are queued and summed by a whole wavefront with __shfl_down.
+// Entries in front of the first owned row belong to a row that started in an
+// earlier tile: their sum goes to carry[b] and csr_stream_carry_fixup adds the
+// carries to y in tile order, so the result does not depend on timing and y
+// needs no zeroing.
+// ---------------------------------------------------------------------------
+template <int VPT>
+__global__ __launch_bounds__(kStreamBlock) void csr_stream_tiles(
+    const int *__restrict__ row_ptr, const int *__restrict__ col_ind, const double *__restrict__ val,
+    const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ tile_row,
+    double *__restrict__ carry, int rows, int nnz, int ntiles, int tiles_per_xcd)
+{
+    constexpr int TILE = kStreamBlock * VPT;
+    constexpr int QCAP = TILE / kLongRow + 1;
+    __shared__ double prod[TILE];
+    __shared__ int long_rows[QCAP];
+    __shared__ int long_count;
+
+    const int b = xcd_contiguous_tile(blockIdx.x, tiles_per_xcd);
+    if (b >= ntiles)
+        return;
+    const int t = threadIdx.x;
+    const long long s = (long long)b * TILE;
+    const int e = (int)(s + TILE < (long long)nnz ? s + TILE : (long long)nnz);
+    if (t == 0)
+        long_count = 0;
+
+    // ---- phase 1: stream + gather + multiply
+    const long long j0 = s + (long long)t * VPT;
+    double p[VPT];
+    if (j0 + VPT <= (long long)nnz) {
+        int c[VPT];
+        double v[VPT];
+#pragma unroll
+        for (int k = 0; k < VPT; k += 4)
+            *reinterpret_cast<int4 *>(&c[k]) = *reinterpret_cast<const int4 *>(col_ind + j0 + k);
+#pragma unroll
+        for (int k = 0; k < VPT; k += 2)
+            *reinterpret_cast<double2 *>(&v[k]) = *reinterpret_cast<const double2 *>(val + j0 + k);
+#pragma unroll
+        for (int k = 0; k < VPT; ++k)
+            p[k] = v[k] * x[c[k]];
+    } else {
+#pragma unroll
+        for (int k = 0; k < VPT; ++k)
+            p[k] = (j0 + k < (long long)nnz) ? val[j0 + k] * x[col_ind[j0 + k]] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < VPT; k += 2)
+        *reinterpret_cast<double2 *>(&prod[t * VPT + k]) = make_double2(p[k], p[k + 1]);
+    __syncthreads();
+
+    // ---- phase 2a: the head of the tile continues an earlier row
+    const int rlo = tile_row[b];
+    const int rhi = tile_row[b + 1];
+    const int lo = (int)s;  // nnz < 2^31
+    if (t < 64) {
+        const int first = rlo < rows ? row_ptr[rlo] : nnz;
+        const int head = (first < e ? first : e) - lo;
+        double acc = 0.0;
+        for (int i = t; i < head; i += 64)
+            acc += prod[i];
+        acc = shfl_down_sum<64>(acc);
+        if (t == 0)
+            carry[b] = acc;
+    }
+
+    // ---- phase 2b: one lane per owned row, long rows deferred
+    for (int r = rlo + t; r < rhi; r += kStreamBlock) {
+        const int a = row_ptr[r];
+        const int nxt = row_ptr[r + 1];
+        const int z = nxt < e ? nxt : e;
+        if (z - a <= kLongRow) {
+            double acc = 0.0;
+            for (int i = a - lo; i < z - lo; ++i)
+                acc += prod[i];
+            y[r] = acc;
+        } else {
+            long_rows[atomicAdd(&long_count, 1)] = r;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2c: one wavefront per long row
+    const int nlong = long_count;
+    const int lane = t & 63;
+    for (int q = t >> 6; q < nlong; q += kStreamBlock / 64) {
+        const int r = long_rows[q];
+        const int a = row_ptr[r];
+        const int nxt = row_ptr[r + 1];
+        const int z = nxt < e ? nxt : e;
+        double acc = 0.0;
+        for (int i = a - lo + lane; i < z - lo; i += 64)
+            acc += prod[i];
+        acc = shfl_down_sum<64>(acc);
+        if (lane == 0)
+            y[r] = acc;
+    }
+}
+
+// One thread per tile; the head of each run of tiles that feed the same row adds
+// their carries to that row in tile order.
+__global__ __launch_bounds__(256) void csr_stream_carry_fixup(
+    const int *__restrict__ carry_row, const double *__restrict__ carry, double *__restrict__ y, int ntiles)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= ntiles)
+        return;
+    const int r = carry_row[b];
+    if (r < 0 || (b > 0 && carry_row[b - 1] == r))
+        return;
+    double acc = y[r];
+    for (int k = b; k < ntiles && carry_row[k] == r; ++k)
+        acc += carry[k];
+    y[r] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// K3: TJDS, column-major.  Thread k of a block is permuted column k0 + k: it
+// keeps x_perm[k] in a register and walks down its column, one jagged diagonal
+// per step, so that at every step the block reads one contiguous run of val /
+// row_ind.  The products scatter into y with hardware fp64 atomics (y zeroed by
+// the caller, like main-cli.c:1008).  Work items cut the (column block,
+// diagonal range) plane into pieces of at most kTjdsBlock x kTjdsDiagChunk
+// entries so the few long columns do not serialise the launch.
+// ---------------------------------------------------------------------------
+template <bool OPERAND_BY_ROW>
+__global__ __launch_bounds__(kTjdsBlock) void tjds_colmajor_scatter(
+    const int *__restrict__ start_pos, const int *__restrict__ row_ind, const double *__restrict__ val,
+    const double *__restrict__ x_perm, double *__restrict__ y, const int4 *__restrict__ work, int cols)
+{
+    const int4 w = work[blockIdx.x];  // x = first column, y = first diagonal, z = one past the last
+    const int k = w.x + threadIdx.x;
+    const double xk = (!OPERAND_BY_ROW && k < cols) ? x_perm[k] : 0.0;
+    for (int d = w.y; d < w.z; ++d) {
+        const int base = start_pos[d];
+        if (k >= start_pos[d + 1] - base)
+            break;  // diagonal lengths never grow with d
+        const int j = base + k;
+        const int r = row_ind[j];
+        // main-cli.c:1018 indexes the permuted operand by the row; the corrected
+        // product uses the column's own entry
+        const double xv = OPERAND_BY_ROW ? x_perm[r] : xk;
+        unsafeAtomicAdd(&y[r], val[j] * xv);
+    }
+}
+
+__global__ __launch_bounds__(256) void tjds_permute_operand(
+    const int *__restrict__ perm, const double *__restrict__ x, double *__restrict__ x_perm, int cols)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < cols)
+        x_perm[k] = x[perm[k]];
+}
+
+__global__ __launch_bounds__(256) void fill_value(double *__restrict__ p, double v, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        p[i] = v;
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+hipError_t launch_csr_vector(int lanes_per_row, const int *row_ptr, const int *col_ind, const double *val,
+                             const double *x, double *y, int rows, hipStream_t stream)
+{
+    if (rows <= 0)
+        return hipSuccess;
+    const long long threads = (long long)rows * lanes_per_row;
+    const unsigned grid = (unsigned)((threads + kVectorBlock - 1) / kVectorBlock);
+#define SMVP_VEC_CASE(T)                                                                              \
+    case T:                                                                                           \
+        hipLaunchKernelGGL(csr_vector_rows<T>, dim3(grid), dim3(kVectorBlock), 0, stream, row_ptr,   \
+                           col_ind, val, x, y, rows);                                                 \
+        break;
+    switch (lanes_per_row) {
+        SMVP_VEC_CASE(2)
+        SMVP_VEC_CASE(4)
+        SMVP_VEC_CASE(8)
+        SMVP_VEC_CASE(16)
+        SMVP_VEC_CASE(32)
+        SMVP_VEC_CASE(64)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef SMVP_VEC_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_csr_stream(int vpt, const int *row_ptr, const int *col_ind, const double *val,
+                             const double *x, double *y, const int *tile_row, const int *carry_row,
+                             double *carry, int rows, int nnz, int ntiles, hipStream_t stream)
+{
+    if (rows <= 0)
+        return hipSuccess;
+    const int tiles_per_xcd = (ntiles + 7) / 8;
+    const unsigned grid = (unsigned)tiles_per_xcd * 8u;
+    switch (vpt) {
+    case 4:
+        hipLaunchKernelGGL(csr_stream_tiles<4>, dim3(grid), dim3(kStreamBlock), 0, stream, row_ptr, col_ind, val,
+                           x, y, tile_row, carry, rows, nnz, ntiles, tiles_per_xcd);
+        break;
+    case 8:
+        hipLaunchKernelGGL(csr_stream_tiles<8>, dim3(grid), dim3(kStreamBlock), 0, stream, row_ptr, col_ind, val,
+                           x, y, tile_row, carry, rows, nnz, ntiles, tiles_per_xcd);
+        break;
+    default:
+        return hipErrorInvalidValue;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return e;
+    if (ntiles > 1) {
+        hipLaunchKernelGGL(csr_stream_carry_fixup, dim3((ntiles + 255) / 256), dim3(256), 0, stream, carry_row,
+                           carry, y, ntiles);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+hipError_t launch_tjds_scatter(bool operand_by_row, const int *start_pos, const int *row_ind, const double *val,
+                               const double *x_perm, double *y, const int4 *work, int nwork, int cols,
+                               hipStream_t stream)
+{
+    if (nwork <= 0)
+        return hipSuccess;
+    if (operand_by_row)
+        hipLaunchKernelGGL(tjds_colmajor_scatter<true>, dim3(nwork), dim3(kTjdsBlock), 0, stream, start_pos,
+                           row_ind, val, x_perm, y, work, cols);
+    else
+        hipLaunchKernelGGL(tjds_colmajor_scatter<false>, dim3(nwork), dim3(kTjdsBlock), 0, stream, start_pos,
+                           row_ind, val, x_perm, y, work, cols);
+    return hipGetLastError();
+}
+
+hipError_t launch_tjds_permute(const int *perm, const double *x, double *x_perm, int cols, hipStream_t stream)
+{
+    if (cols <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(tjds_permute_operand, dim3((cols + 255) / 256), dim3(256), 0, stream, perm, x, x_perm, cols);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill(double *p, double v, long long n, hipStream_t stream)
+{
+    if (n <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(fill_value, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, v, n);
+    return hipGetLastError();
+}
+
+}  // namespace smvp

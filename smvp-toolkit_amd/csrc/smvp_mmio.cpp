@@ -1,0 +1,230 @@
+// smvp_mmio.cpp -- Matrix Market coordinate reader for the CLI path.
+//
+// Fresh implementation of the three input steps the reference CLI performs:
+//   banner     mm_read_banner          mmio/mmio.c:96-170
+//   size line  mm_read_mtx_crd_size    mmio/mmio.c:180-208
+//   entries    the loop in main()      main-cli.c:1426-1441
+// Same accept/reject behaviour and return codes; the entry reader slurps the
+// rest of the stream and tokenises it in memory instead of one fscanf per entry.
+#include "smvp_common.h"
+
+#include <cctype>
+#include <cerrno>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr size_t kMaxLine = 1025;  // MM_MAX_LINE_LENGTH, mmio/mmio.h:13
+
+// Splits on blanks like scanf's %s; returns the number of tokens found (<= want).
+int split_tokens(const char *line, std::string *tok, int want)
+{
+    int n = 0;
+    const char *p = line;
+    while (n < want) {
+        while (*p && isspace((unsigned char)*p))
+            ++p;
+        if (!*p)
+            break;
+        const char *q = p;
+        while (*q && !isspace((unsigned char)*q))
+            ++q;
+        tok[n++].assign(p, q);
+        p = q;
+    }
+    return n;
+}
+
+void to_lower(std::string &s)
+{
+    for (char &c : s)
+        c = (char)tolower((unsigned char)c);
+}
+
+// strtol-based "%d": skips blanks, needs at least one digit.
+bool take_int(const char *&p, const char *end, int *out)
+{
+    while (p < end && isspace((unsigned char)*p))
+        ++p;
+    if (p >= end)
+        return false;
+    char *stop = nullptr;
+    errno = 0;
+    long v = strtol(p, &stop, 10);
+    if (stop == p)
+        return false;
+    *out = (int)v;
+    p = stop;
+    return true;
+}
+
+bool take_double(const char *&p, const char *end, double *out)
+{
+    while (p < end && isspace((unsigned char)*p))
+        ++p;
+    if (p >= end)
+        return false;
+    char *stop = nullptr;
+    double v = strtod(p, &stop);
+    if (stop == p)
+        return false;
+    *out = v;
+    p = stop;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int smvp_mm_read_banner(FILE *f, smvp_mm_typecode *matcode)
+{
+    if (!f || !matcode)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_mm_read_banner: null argument");
+    char *tc = *matcode;
+    tc[0] = tc[1] = tc[2] = ' ';
+    tc[3] = 'G';
+
+    char line[kMaxLine];
+    if (!fgets(line, sizeof line, f))
+        return smvp::fail(SMVP_MM_PREMATURE_EOF, "matrix market: empty file");
+    std::string t[5];
+    if (split_tokens(line, t, 5) != 5)
+        return smvp::fail(SMVP_MM_PREMATURE_EOF, "matrix market: banner needs five fields");
+    for (int i = 1; i < 5; ++i)
+        to_lower(t[i]);
+
+    if (t[0].compare(0, 14, "%%MatrixMarket") != 0)
+        return smvp::fail(SMVP_MM_NO_HEADER, "matrix market: missing %%%%MatrixMarket banner");
+    if (t[1] != "matrix")
+        return smvp::fail(SMVP_MM_UNSUPPORTED_TYPE, "matrix market: object '%s'", t[1].c_str());
+    tc[0] = 'M';
+
+    if (t[2] == "coordinate")
+        tc[1] = 'C';
+    else if (t[2] == "array")
+        tc[1] = 'A';
+    else
+        return smvp::fail(SMVP_MM_UNSUPPORTED_TYPE, "matrix market: format '%s'", t[2].c_str());
+
+    static const struct { const char *name; char code; } fields[] = {
+        {"real", 'R'}, {"complex", 'C'}, {"pattern", 'P'}, {"integer", 'I'}};
+    static const struct { const char *name; char code; } symm[] = {
+        {"general", 'G'}, {"symmetric", 'S'}, {"hermitian", 'H'}, {"skew-symmetric", 'K'}};
+    char fcode = 0, scode = 0;
+    for (auto &e : fields)
+        if (t[3] == e.name)
+            fcode = e.code;
+    if (!fcode)
+        return smvp::fail(SMVP_MM_UNSUPPORTED_TYPE, "matrix market: field '%s'", t[3].c_str());
+    tc[2] = fcode;
+    for (auto &e : symm)
+        if (t[4] == e.name)
+            scode = e.code;
+    if (!scode)
+        return smvp::fail(SMVP_MM_UNSUPPORTED_TYPE, "matrix market: symmetry '%s'", t[4].c_str());
+    tc[3] = scode;
+    return SMVP_OK;
+}
+
+extern "C" int smvp_mm_read_mtx_crd_size(FILE *f, int *rows, int *cols, int *nnz)
+{
+    if (!f || !rows || !cols || !nnz)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_mm_read_mtx_crd_size: null argument");
+    *rows = *cols = *nnz = 0;
+    char line[kMaxLine];
+    do {
+        if (!fgets(line, sizeof line, f))
+            return smvp::fail(SMVP_MM_PREMATURE_EOF, "matrix market: no size line");
+    } while (line[0] == '%');
+
+    const char *p = line, *end = line + strlen(line);
+    int v[3];
+    if (take_int(p, end, &v[0]) && take_int(p, end, &v[1]) && take_int(p, end, &v[2])) {
+        *rows = v[0], *cols = v[1], *nnz = v[2];
+        return SMVP_OK;
+    }
+    // A blank (or short) line after the comments: mmio keeps pulling integers
+    // off the stream until it has three (mmio/mmio.c:200-205).
+    int have = 0;
+    for (;;) {
+        int c = fgetc(f);
+        if (c == EOF)
+            return smvp::fail(SMVP_MM_PREMATURE_EOF, "matrix market: no size line");
+        if (isspace(c))
+            continue;
+        ungetc(c, f);
+        int val;
+        if (fscanf(f, "%d", &val) == 1) {
+            v[have++] = val;
+            if (have == 3)
+                break;
+        } else {
+            have = 0;  // mmio restarts its three-field scan after a mismatch
+            fgetc(f);
+        }
+    }
+    *rows = v[0], *cols = v[1], *nnz = v[2];
+    return SMVP_OK;
+}
+
+extern "C" int smvp_mm_read_coo_entries(FILE *f, const smvp_mm_typecode matcode, int nnz, smvp_coo_t *out)
+{
+    if (!f || !matcode || nnz < 0 || (nnz > 0 && !out))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_mm_read_coo_entries: bad argument");
+    // Everything after the size line, in one buffer.
+    std::vector<char> buf;
+    {
+        char chunk[1 << 16];
+        size_t got;
+        while ((got = fread(chunk, 1, sizeof chunk, f)) > 0)
+            buf.insert(buf.end(), chunk, chunk + got);
+        buf.push_back('\0');
+    }
+    const char *p = buf.data(), *end = buf.data() + buf.size() - 1;
+    const bool pattern = (matcode[2] == 'P');
+    for (int i = 0; i < nnz; ++i) {
+        int r, c;
+        double v = 1.0;  // main-cli.c:1432
+        if (!take_int(p, end, &r) || !take_int(p, end, &c) || (!pattern && !take_double(p, end, &v)))
+            return smvp::fail(SMVP_MM_PREMATURE_EOF, "matrix market: entry %d of %d is missing or malformed", i + 1, nnz);
+        out[i].row = r - 1;  // main-cli.c:1439-1440
+        out[i].col = c - 1;
+        out[i].val = v;
+    }
+    return SMVP_OK;
+}
+
+extern "C" int smvp_mm_read_header_path(const char *path, smvp_mm_typecode *matcode, int *rows, int *cols, int *nnz)
+{
+    if (!path)
+        return smvp::fail(SMVP_ERR_INVALID, "null path");
+    FILE *f = fopen(path, "r");
+    if (!f)
+        return smvp::fail(SMVP_ERR_IO, "cannot open %s", path);
+    int rc = smvp_mm_read_banner(f, matcode);
+    if (rc == SMVP_OK)
+        rc = smvp_mm_read_mtx_crd_size(f, rows, cols, nnz);
+    fclose(f);
+    return rc;
+}
+
+extern "C" int smvp_mm_read_coo_path(const char *path, smvp_coo_t *out, int capacity,
+                                     smvp_mm_typecode *matcode, int *rows, int *cols, int *nnz)
+{
+    if (!path)
+        return smvp::fail(SMVP_ERR_INVALID, "null path");
+    FILE *f = fopen(path, "r");
+    if (!f)
+        return smvp::fail(SMVP_ERR_IO, "cannot open %s", path);
+    int rc = smvp_mm_read_banner(f, matcode);
+    if (rc == SMVP_OK)
+        rc = smvp_mm_read_mtx_crd_size(f, rows, cols, nnz);
+    if (rc == SMVP_OK && *nnz > capacity)
+        rc = smvp::fail(SMVP_ERR_INVALID, "capacity %d < nnz %d", capacity, *nnz);
+    if (rc == SMVP_OK)
+        rc = smvp_mm_read_coo_entries(f, *matcode, *nnz, out);
+    fclose(f);
+    return rc;
+}

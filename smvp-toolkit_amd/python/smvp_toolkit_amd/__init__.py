@@ -1,0 +1,394 @@
+"""ctypes binding for libsmvp_amd.so (include/smvp_amd.h).
+
+The product is the C-ABI library plus the C command-line program; this module
+only exposes that ABI to Python for the tests and for bench.py.  It holds no
+compute of its own and there is no fallback: if the library is missing, or no
+HIP device is visible, the calls fail.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))          # smvp-toolkit_amd/
+REPO_ROOT = os.path.dirname(PKG_ROOT)
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libsmvp_amd.so")
+CLI_PATH = os.path.join(PKG_ROOT, "bin", "smvp-toolkit-cli")
+
+OK = 0
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_IO, ERR_UNSUPPORTED = 1, 2, 3, 4, 5, 6
+MM_COULD_NOT_READ_FILE, MM_PREMATURE_EOF, MM_NOT_MTX, MM_NO_HEADER, MM_UNSUPPORTED_TYPE = 11, 12, 13, 14, 15
+CSR_KERNEL_AUTO, CSR_KERNEL_VECTOR, CSR_KERNEL_STREAM = 0, 1, 2
+MEM_HOST, MEM_DEVICE = 0, 1
+SYNTH_MEMPLUS_SHAPED, SYNTH_UNIFORM = 1, 2
+
+COO_DTYPE = np.dtype([("row", "<i4"), ("col", "<i4"), ("val", "<f8")], align=True)
+
+
+class TimeStats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("time_total", "time_avg", "time_stdev", "time_min", "time_max")]
+
+
+class RunOpts(C.Structure):
+    _fields_ = [("device", C.c_int), ("csr_kernel", C.c_int), ("csr_param", C.c_int),
+                ("tjds_ref_quirks", C.c_int), ("use_graph", C.c_int), ("x", C.c_void_p)]
+
+
+class SmvpError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib().smvp_last_error().decode(errors="replace")
+        super().__init__("%s failed with status %d: %s" % (where, code, msg))
+
+
+_lib = None
+
+# every symbol include/smvp_amd.h declares; tests check that all of them resolve
+EXPORTS = [
+    "smvp_last_error", "smvp_version_string",
+    "smvp_mm_read_banner", "smvp_mm_read_mtx_crd_size", "smvp_mm_read_coo_entries",
+    "smvp_mm_read_header_path", "smvp_mm_read_coo_path",
+    "smvp_csr_from_coo", "smvp_tjds_from_coo",
+    "smvp_device_count", "smvp_device_info",
+    "smvp_csr_create", "smvp_csr_set_kernel", "smvp_csr_get_kernel", "smvp_csr_spmv",
+    "smvp_csr_describe", "smvp_csr_destroy",
+    "smvp_tjds_create", "smvp_tjds_set_x", "smvp_tjds_zero_y", "smvp_tjds_spmv",
+    "smvp_tjds_set_ref_quirks", "smvp_tjds_describe", "smvp_tjds_destroy",
+    "smvp_run_opts_default", "smvp_csr_compute", "smvp_tjds_compute",
+    "smvp_time_stats", "smvp_generate_report_text",
+    "smvp_synth_row_lengths", "smvp_synth_fill", "smvp_partition_rows",
+]
+
+
+def lib():
+    """The loaded library.  Raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "or `make -C smvp-toolkit_amd` first" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.smvp_last_error.restype = C.c_char_p
+        L.smvp_version_string.restype = C.c_char_p
+        vp, ci = C.c_void_p, C.c_int
+        L.smvp_csr_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, vp, vp, vp, ci, vp]
+        L.smvp_csr_set_kernel.argtypes = [vp, ci, ci]
+        L.smvp_csr_get_kernel.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
+        L.smvp_csr_spmv.argtypes = [vp, vp, vp, vp]
+        L.smvp_csr_describe.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double)]
+        L.smvp_csr_destroy.argtypes = [vp]
+        L.smvp_csr_destroy.restype = None
+        L.smvp_tjds_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, ci, vp, vp, vp, vp, ci]
+        L.smvp_tjds_set_x.argtypes = [vp, vp, vp]
+        L.smvp_tjds_zero_y.argtypes = [vp, vp, vp]
+        L.smvp_tjds_spmv.argtypes = [vp, vp, vp]
+        L.smvp_tjds_set_ref_quirks.argtypes = [vp, ci, ci, ci]
+        L.smvp_tjds_describe.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double)]
+        L.smvp_tjds_destroy.argtypes = [vp]
+        L.smvp_tjds_destroy.restype = None
+        L.smvp_csr_from_coo.argtypes = [vp, ci, ci, vp, vp, vp]
+        L.smvp_tjds_from_coo.argtypes = [vp, ci, ci, ci, vp, vp, ci, vp, vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+        L.smvp_csr_compute.argtypes = [vp, ci, ci, ci, ci, C.POINTER(RunOpts), vp, vp, C.POINTER(TimeStats)]
+        L.smvp_tjds_compute.argtypes = [vp, ci, ci, ci, ci, C.POINTER(RunOpts), vp, vp, C.POINTER(TimeStats)]
+        L.smvp_run_opts_default.argtypes = [C.POINTER(RunOpts)]
+        L.smvp_run_opts_default.restype = None
+        L.smvp_time_stats.argtypes = [vp, ci, C.POINTER(TimeStats)]
+        L.smvp_generate_report_text.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, ci, ci, ci, vp,
+                                                C.POINTER(TimeStats), C.c_ulong, C.c_char_p, C.c_size_t]
+        i64, u64 = C.c_int64, C.c_uint64
+        L.smvp_synth_row_lengths.argtypes = [ci, u64, i64, i64, ci, i64, i64, vp]
+        L.smvp_synth_fill.argtypes = [ci, u64, i64, i64, ci, i64, i64, vp, vp, vp, ci]
+        L.smvp_partition_rows.argtypes = [vp, ci, ci, vp]
+        L.smvp_mm_read_header_path.argtypes = [C.c_char_p, vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+        L.smvp_mm_read_coo_path.argtypes = [C.c_char_p, vp, ci, vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+        L.smvp_device_count.argtypes = [C.POINTER(ci)]
+        L.smvp_device_info.argtypes = [ci, C.c_char_p, C.c_size_t, C.POINTER(ci), C.POINTER(C.c_size_t)]
+        _lib = L
+    return _lib
+
+
+def _check(code, where):
+    if code != OK:
+        raise SmvpError(code, where)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _arr(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a if a.size else np.zeros(1, dtype=dtype)
+
+
+# ---------------------------------------------------------------- Matrix Market
+def mm_read_header(path):
+    """-> (status, typecode str, rows, cols, nnz); status is an mmio code, not raised."""
+    tc = C.create_string_buffer(4)
+    m, n, nz = C.c_int(), C.c_int(), C.c_int()
+    rc = lib().smvp_mm_read_header_path(os.fsencode(path), C.cast(tc, C.c_void_p), C.byref(m), C.byref(n), C.byref(nz))
+    return rc, tc.raw.decode(), m.value, n.value, nz.value
+
+
+def mm_read_coo(path):
+    """-> (typecode, rows, cols, coo structured array).  Raises SmvpError on a bad file."""
+    rc, tc, m, n, nz = mm_read_header(path)
+    _check(rc, "smvp_mm_read_header_path")
+    coo = np.zeros(max(nz, 1), dtype=COO_DTYPE)
+    tcb = C.create_string_buffer(4)
+    mm, nn, nzz = C.c_int(), C.c_int(), C.c_int()
+    _check(lib().smvp_mm_read_coo_path(os.fsencode(path), _p(coo), nz, C.cast(tcb, C.c_void_p), C.byref(mm),
+                                       C.byref(nn), C.byref(nzz)), "smvp_mm_read_coo_path")
+    return tcb.raw.decode(), mm.value, nn.value, coo[:nz]
+
+
+def make_coo(rows_idx, cols_idx, vals):
+    coo = np.zeros(len(rows_idx), dtype=COO_DTYPE)
+    coo["row"], coo["col"], coo["val"] = rows_idx, cols_idx, vals
+    return coo
+
+
+# ------------------------------------------------------------------ conversion
+def csr_from_coo(coo, rows):
+    coo = np.ascontiguousarray(coo, dtype=COO_DTYPE)
+    nnz = len(coo)
+    row_ptr = np.zeros(rows + 1, dtype=np.int32)
+    col_ind = np.zeros(max(nnz, 1), dtype=np.int32)
+    val = np.zeros(max(nnz, 1), dtype=np.float64)
+    _check(lib().smvp_csr_from_coo(_p(_arr(coo, COO_DTYPE)), rows, nnz, _p(row_ptr), _p(col_ind), _p(val)),
+           "smvp_csr_from_coo")
+    return row_ptr, col_ind[:nnz], val[:nnz]
+
+
+class TjdsArrays:
+    """perm / start_pos / row_ind / val plus the two reference-quirk scalars."""
+
+
+def tjds_from_coo(coo, rows, cols):
+    coo = np.ascontiguousarray(coo, dtype=COO_DTYPE)
+    nnz = len(coo)
+    t = TjdsArrays()
+    t.rows, t.cols, t.nnz = rows, cols, nnz
+    perm = np.zeros(max(cols, 1), dtype=np.int32)
+    cap = max(rows, nnz) + 2
+    sp = np.zeros(cap, dtype=np.int32)
+    row_ind = np.zeros(max(nnz, 1), dtype=np.int32)
+    val = np.zeros(max(nnz, 1), dtype=np.float64)
+    nd, rn, ls = C.c_int(), C.c_int(), C.c_int()
+    _check(lib().smvp_tjds_from_coo(_p(_arr(coo, COO_DTYPE)), rows, cols, nnz, _p(perm), _p(sp), cap, _p(row_ind),
+                                    _p(val), C.byref(nd), C.byref(rn), C.byref(ls)), "smvp_tjds_from_coo")
+    t.num_diag, t.ref_num_tjdiag, t.last_diag_single = nd.value, rn.value, ls.value
+    t.perm, t.start_pos = perm[:cols], sp[:t.num_diag + 1].copy()
+    t.row_ind, t.val = row_ind[:nnz], val[:nnz]
+    return t
+
+
+def partition_rows(row_ptr, parts):
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int32)
+    bounds = np.zeros(parts + 1, dtype=np.int32)
+    _check(lib().smvp_partition_rows(_p(row_ptr), len(row_ptr) - 1, parts, _p(bounds)), "smvp_partition_rows")
+    return bounds
+
+
+# ------------------------------------------------------------------- synthetic
+def synth_csr(kind, seed, rows_total, cols_total, param=0, row_begin=0, row_end=None, threads=None):
+    """Row block [row_begin, row_end) of a synthetic matrix -> (row_ptr, col_ind, val), local row numbering."""
+    row_end = rows_total if row_end is None else row_end
+    n = row_end - row_begin
+    lens = np.zeros(max(n, 1), dtype=np.int32)
+    _check(lib().smvp_synth_row_lengths(kind, seed, rows_total, cols_total, param, row_begin, row_end, _p(lens)),
+           "smvp_synth_row_lengths")
+    row_ptr64 = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens[:n], out=row_ptr64[1:])
+    if row_ptr64[-1] >= 2 ** 31:
+        raise ValueError("row block holds %d entries: 32-bit indices (the reference's) cannot address it" % row_ptr64[-1])
+    row_ptr = row_ptr64.astype(np.int32)
+    nnz = int(row_ptr[-1])
+    col_ind = np.empty(max(nnz, 1), dtype=np.int32)
+    val = np.empty(max(nnz, 1), dtype=np.float64)
+    if threads is None:
+        threads = max(1, min(16, (os.cpu_count() or 1)))
+    _check(lib().smvp_synth_fill(kind, seed, rows_total, cols_total, param, row_begin, row_end, _p(row_ptr),
+                                 _p(col_ind), _p(val), threads), "smvp_synth_fill")
+    return row_ptr, col_ind[:nnz], val[:nnz]
+
+
+# ---------------------------------------------------------------------- device
+def device_count():
+    n = C.c_int()
+    _check(lib().smvp_device_count(C.byref(n)), "smvp_device_count")
+    return n.value
+
+
+def device_info(device=0):
+    name = C.create_string_buffer(256)
+    cus, mem = C.c_int(), C.c_size_t()
+    _check(lib().smvp_device_info(device, name, 256, C.byref(cus), C.byref(mem)), "smvp_device_info")
+    return name.value.decode(), cus.value, mem.value
+
+
+def _dev_ptr(t):
+    """Device address of a torch tensor (or a raw int address)."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return None
+    if isinstance(stream, int):
+        return C.c_void_p(stream)
+    return C.c_void_p(stream.cuda_stream)   # torch.cuda.Stream
+
+
+class CsrMatrix:
+    """Device-resident CSR matrix (smvp_csr_t).  Arrays may be numpy (copied to HBM) or torch CUDA tensors (adopted)."""
+
+    def __init__(self, rows, cols, row_ptr, col_ind, val, device=0):
+        self.rows, self.cols = rows, cols
+        self._h = C.c_void_p()
+        self._keep = None
+        if isinstance(row_ptr, np.ndarray):
+            rp, ci, v = _arr(row_ptr, np.int32), _arr(col_ind, np.int32), _arr(val, np.float64)
+            self.nnz = int(rp[rows]) if rows >= 0 else 0
+            _check(lib().smvp_csr_create(C.byref(self._h), device, rows, cols, self.nnz, _p(rp), _p(ci), _p(v),
+                                         MEM_HOST, None), "smvp_csr_create")
+        else:
+            host_rp = _arr(row_ptr.cpu().numpy(), np.int32)
+            self.nnz = int(host_rp[rows])
+            self._keep = (row_ptr, col_ind, val)
+            _check(lib().smvp_csr_create(C.byref(self._h), device, rows, cols, self.nnz, _dev_ptr(row_ptr),
+                                         _dev_ptr(col_ind), _dev_ptr(val), MEM_DEVICE, _p(host_rp)),
+                   "smvp_csr_create")
+
+    def set_kernel(self, kernel, param=0):
+        _check(lib().smvp_csr_set_kernel(self._h, kernel, param), "smvp_csr_set_kernel")
+
+    def get_kernel(self):
+        k, p = C.c_int(), C.c_int()
+        _check(lib().smvp_csr_get_kernel(self._h, C.byref(k), C.byref(p)), "smvp_csr_get_kernel")
+        return k.value, p.value
+
+    def spmv(self, x, y, stream=None):
+        """y = A x, asynchronous on `stream`; x, y are torch CUDA float64 tensors."""
+        _check(lib().smvp_csr_spmv(self._h, _dev_ptr(x), _dev_ptr(y), _stream_ptr(stream)), "smvp_csr_spmv")
+
+    def describe(self):
+        name = C.create_string_buffer(128)
+        b = C.c_double()
+        _check(lib().smvp_csr_describe(self._h, name, 128, C.byref(b)), "smvp_csr_describe")
+        return name.value.decode(), b.value
+
+    def close(self):
+        if self._h:
+            lib().smvp_csr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TjdsMatrix:
+    """Device-resident TJDS matrix (smvp_tjds_t) built from TjdsArrays."""
+
+    def __init__(self, t, device=0):
+        self.rows, self.cols, self.nnz = t.rows, t.cols, t.nnz
+        self._t = t
+        self._h = C.c_void_p()
+        _check(lib().smvp_tjds_create(C.byref(self._h), device, t.rows, t.cols, t.nnz, t.num_diag,
+                                      _p(_arr(t.perm, np.int32)), _p(_arr(t.start_pos, np.int32)),
+                                      _p(_arr(t.row_ind, np.int32)), _p(_arr(t.val, np.float64)), MEM_HOST),
+               "smvp_tjds_create")
+
+    def set_x(self, x, stream=None):
+        _check(lib().smvp_tjds_set_x(self._h, _dev_ptr(x), _stream_ptr(stream)), "smvp_tjds_set_x")
+
+    def zero_y(self, y, stream=None):
+        _check(lib().smvp_tjds_zero_y(self._h, _dev_ptr(y), _stream_ptr(stream)), "smvp_tjds_zero_y")
+
+    def spmv(self, y, stream=None):
+        _check(lib().smvp_tjds_spmv(self._h, _dev_ptr(y), _stream_ptr(stream)), "smvp_tjds_spmv")
+
+    def set_ref_quirks(self, enable=True):
+        _check(lib().smvp_tjds_set_ref_quirks(self._h, int(enable), self._t.ref_num_tjdiag,
+                                              self._t.last_diag_single), "smvp_tjds_set_ref_quirks")
+
+    def describe(self):
+        name = C.create_string_buffer(128)
+        b = C.c_double()
+        _check(lib().smvp_tjds_describe(self._h, name, 128, C.byref(b)), "smvp_tjds_describe")
+        return name.value.decode(), b.value
+
+    def close(self):
+        if self._h:
+            lib().smvp_tjds_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------- reference-shaped entry points
+def _run_opts(device, csr_kernel, csr_param, ref_quirks, x):
+    o = RunOpts()
+    lib().smvp_run_opts_default(C.byref(o))
+    o.device, o.csr_kernel, o.csr_param, o.tjds_ref_quirks = device, csr_kernel, csr_param, int(ref_quirks)
+    keep = None
+    if x is not None:
+        keep = _arr(x, np.float64)
+        o.x = keep.ctypes.data
+    return o, keep
+
+
+def csr_compute(coo, rows, cols, iters=1, device=0, kernel=CSR_KERNEL_AUTO, param=0, x=None):
+    """smvp_csr_compute: COO in, (y, per-iteration ms, TimeStats) out."""
+    nnz = len(coo)
+    coo = _arr(coo, COO_DTYPE)
+    y = np.zeros(max(rows, 1), dtype=np.float64)
+    ms = np.zeros(iters, dtype=np.float64)
+    st = TimeStats()
+    o, keep = _run_opts(device, kernel, param, False, x)
+    _check(lib().smvp_csr_compute(_p(coo), rows, cols, nnz, iters, C.byref(o), _p(y), _p(ms), C.byref(st)),
+           "smvp_csr_compute")
+    return y[:rows], ms, st
+
+
+def tjds_compute(coo, rows, cols, iters=1, device=0, ref_quirks=False, x=None):
+    """smvp_tjds_compute: COO in, (y, per-iteration ms, TimeStats) out."""
+    nnz = len(coo)
+    coo = _arr(coo, COO_DTYPE)
+    y = np.zeros(max(rows, 1), dtype=np.float64)
+    ms = np.zeros(iters, dtype=np.float64)
+    st = TimeStats()
+    o, keep = _run_opts(device, CSR_KERNEL_AUTO, 0, ref_quirks, x)
+    _check(lib().smvp_tjds_compute(_p(coo), rows, cols, nnz, iters, C.byref(o), _p(y), _p(ms), C.byref(st)),
+           "smvp_tjds_compute")
+    return y[:rows], ms, st
+
+
+# -------------------------------------------------------------- stats + report
+def time_stats(ms):
+    ms = _arr(ms, np.float64)
+    st = TimeStats()
+    _check(lib().smvp_time_stats(_p(ms), len(ms), C.byref(st)), "smvp_time_stats")
+    return st
+
+
+def generate_report_text(input_name, report_dir, alg_name, nnz, y, iters, stats, unix_time=0):
+    rows = len(y)
+    y = _arr(y, np.float64)
+    out = C.create_string_buffer(4096)
+    _check(lib().smvp_generate_report_text(os.fsencode(input_name), os.fsencode(report_dir or ""),
+                                           alg_name.encode(), nnz, rows, iters, _p(y), C.byref(stats),
+                                           unix_time, out, 4096), "smvp_generate_report_text")
+    return out.value.decode()

@@ -1,0 +1,54 @@
+"""Row-block sharding of one SpMV across the GPUs of a node.
+
+Rank g owns rows [bounds[g], bounds[g+1]) of A -- its own slice of val/col_ind, a
+rebased row_ptr, the whole operand x -- and produces that slice of y.  The one
+exchange step is an all-gather of the y slices (RCCL over xGMI on the GPUs,
+gloo in the CPU tests).  The reference has no counterpart: it is one thread.
+"""
+import numpy as np
+
+
+def equal_row_bounds(rows_total, world):
+    """Row blocks of (almost) equal height: good when row lengths are i.i.d."""
+    return np.array([rows_total * g // world for g in range(world + 1)], dtype=np.int64)
+
+
+def gather_counts(bounds):
+    """(rows per rank, padded block height used on the wire)."""
+    counts = np.diff(bounds)
+    return counts, int(counts.max()) if len(counts) else 0
+
+
+def allgather_y(dist, y_local, y_full, bounds, wire=None, group=None):
+    """All-gather the row blocks of y into y_full (length bounds[-1]) on every rank.
+
+    Equal blocks go straight into y_full with one all_gather_into_tensor.  Unequal
+    blocks (nnz-balanced partitions) travel padded to the tallest block through
+    `wire` (world * pad elements) and are compacted afterwards.
+    """
+    import torch
+
+    counts, pad = gather_counts(bounds)
+    world = len(counts)
+    if world == 1:
+        y_full[:counts[0]].copy_(y_local[:counts[0]])
+        return y_full
+    if int(counts.min()) == pad:
+        dist.all_gather_into_tensor(y_full[:pad * world], y_local[:pad], group=group)
+        return y_full
+    if wire is None:
+        wire = torch.empty(world * pad, dtype=y_local.dtype, device=y_local.device)
+    send = y_local
+    if y_local.numel() != pad:
+        send = torch.zeros(pad, dtype=y_local.dtype, device=y_local.device)
+        send[:y_local.numel()].copy_(y_local)
+    dist.all_gather_into_tensor(wire, send, group=group)
+    for g in range(world):
+        y_full[int(bounds[g]):int(bounds[g + 1])].copy_(wire[g * pad:g * pad + int(counts[g])])
+    return y_full
+
+
+def slice_csr(row_ptr, col_ind, val, r0, r1):
+    """Rows [r0, r1) of a host CSR matrix with row_ptr rebased to 0."""
+    a, b = int(row_ptr[r0]), int(row_ptr[r1])
+    return (row_ptr[r0:r1 + 1] - row_ptr[r0]).astype(np.int32), col_ind[a:b], val[a:b]

@@ -1,0 +1,378 @@
+"""GPU parity: the HIP kernels, called through the C ABI, against the CPU oracle.
+
+Tolerances (BASELINE.json north_star):
+  - integer arrays (row_ptr/col_ind, perm/start_pos/row_ind): bit-exact -- checked on the host
+    in test_host_library.py; here the same arrays feed the kernels.
+  - fp64 y: |y_gpu[r] - y_ref[r]| <= 1e-9 * sum_j |a_rj x_j| for every row (row-normwise relative;
+    memplus has ~200 rows whose true sum cancels to ~1e-15 of their terms, so an element-wise
+    relative bound cannot hold for ANY summation order other than the serial one).
+  - pattern matrices (ibm32, curtis54, pwt) and pdp08-pg4 have small-integer sums: exact.
+  - rows the stream kernel sums with one lane are bit-identical to the serial oracle.
+"""
+import os
+import re
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import smvp_toolkit_amd as sm
+from conftest import REPORTS, SAMPLES
+from test_oracle_golden import _mask
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+EXACT = {"ibm32.mtx", "curtis54.mtx", "pwt.mtx", "pdp08-pg4.mtx"}
+
+CSR_VARIANTS = [(sm.CSR_KERNEL_STREAM, 1024), (sm.CSR_KERNEL_STREAM, 2048)] + \
+               [(sm.CSR_KERNEL_VECTOR, t) for t in (2, 4, 8, 16, 32, 64)]
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def row_scale(row_ptr, col_ind, val, x):
+    """sum_j |a_rj x_j| per row -- the yardstick of the normwise bound."""
+    return ob.csr_spmv(row_ptr, col_ind, np.abs(val), np.abs(x))
+
+
+def assert_close(y, ref, scale, exact=False):
+    assert y.shape == ref.shape
+    if exact:
+        assert np.array_equal(y, ref)
+    else:
+        bad = np.abs(y - ref) > TOL * scale
+        assert not bad.any(), "%d rows beyond %g * sum|a x|; worst %g" % (
+            bad.sum(), TOL, (np.abs(y - ref) / np.maximum(scale, 1e-300)).max())
+
+
+def gpu_csr(torch, rows, cols, row_ptr, col_ind, val, x, kernel, param):
+    A = sm.CsrMatrix(rows, cols, row_ptr, col_ind, val)
+    A.set_kernel(kernel, param)
+    assert A.get_kernel() == (kernel, param)
+    dx = dev(torch, x)
+    dy = torch.full((max(rows, 1),), float("nan"), dtype=torch.float64, device="cuda")
+    A.spmv(dx, dy)
+    torch.cuda.synchronize()
+    A.close()
+    return dy.cpu().numpy()[:rows]
+
+
+def load(name):
+    tc, m, n, coo = sm.mm_read_coo(ob.fixture_path(name))
+    return m, n, coo
+
+
+# --------------------------------------------------------------- sample matrices
+@pytest.mark.parametrize("name", SAMPLES)
+@pytest.mark.parametrize("kernel,param", CSR_VARIANTS)
+def test_csr_sample_matrices_ones(torch, name, kernel, param):
+    m, n, coo = load(name)
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    x = np.ones(n)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+    y = gpu_csr(torch, m, n, row_ptr, col_ind, val, x, kernel, param)
+    assert_close(y, ref, row_scale(row_ptr, col_ind, val, x), exact=name in EXACT)
+    if name in EXACT or kernel == sm.CSR_KERNEL_STREAM:
+        # the %g text of the report must equal the reference's committed report
+        want = ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_%s.txt" % REPORTS[name][0]))
+        got = ob.fmt_g(y)
+        if name in EXACT:
+            assert got == want
+
+
+@pytest.mark.parametrize("name", SAMPLES)
+@pytest.mark.parametrize("kernel,param", CSR_VARIANTS)
+def test_csr_sample_matrices_general_x(torch, name, kernel, param):
+    m, n, coo = load(name)
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    x = np.random.default_rng(67890).random(n)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+    y = gpu_csr(torch, m, n, row_ptr, col_ind, val, x, kernel, param)
+    assert_close(y, ref, row_scale(row_ptr, col_ind, val, x))
+
+
+def test_stream_kernel_is_bitwise_serial_on_short_rows(torch):
+    """Rows that fit one tile and are summed by one lane reproduce the serial loop bit for bit."""
+    m, n, coo = load("memplus.mtx")
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    x = np.random.default_rng(1).random(n)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+    y = gpu_csr(torch, m, n, row_ptr, col_ind, val, x, sm.CSR_KERNEL_STREAM, 1024)
+    lens = np.diff(row_ptr)
+    tile_of_first = row_ptr[:-1] // 1024
+    tile_of_last = (np.maximum(row_ptr[1:], 1) - 1) // 1024
+    one_lane = (lens <= 32) & (tile_of_first == tile_of_last)
+    assert one_lane.mean() > 0.9
+    assert np.array_equal(y[one_lane], ref[one_lane])
+
+
+@pytest.mark.parametrize("name", SAMPLES)
+def test_tjds_sample_matrices(torch, name):
+    m, n, coo = load(name)
+    t = sm.tjds_from_coo(coo, m, n)
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    T = sm.TjdsMatrix(t)
+    for x in (np.ones(n), np.random.default_rng(67890).random(n)):
+        ref = ob.csr_spmv(row_ptr, col_ind, val, x)          # a correct TJDS computes A x
+        dy = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+        T.set_x(dev(torch, x))
+        T.zero_y(dy)
+        T.spmv(dy)
+        torch.cuda.synchronize()
+        y = dy.cpu().numpy()
+        assert_close(y, ref, row_scale(row_ptr, col_ind, val, x), exact=(name in EXACT and x[0] == 1.0))
+        assert_close(y, ob.tjds_spmv(ob.tjds_build(coo, m, n), x), row_scale(row_ptr, col_ind, val, x))
+    T.close()
+
+
+@pytest.mark.parametrize("name", [s for s in SAMPLES if REPORTS[s][1]])
+def test_tjds_ref_quirks_reproduce_committed_reports(torch, name):
+    """--ref-quirks: same kernel, host-edited plan, reproduces the reference's (defective) TJDS reports."""
+    m, n, coo = load(name)
+    t = sm.tjds_from_coo(coo, m, n)
+    T = sm.TjdsMatrix(t)
+    T.set_ref_quirks(True)
+    dy = torch.zeros(m, dtype=torch.float64, device="cuda")
+    T.set_x(dev(torch, np.ones(n)))
+    T.zero_y(dy)
+    T.spmv(dy)
+    torch.cuda.synchronize()
+    y = dy.cpu().numpy()
+    want = ob.report_y_lines(ob.read_report("smvp-toolbox_report_TJDS_%s.txt" % REPORTS[name][1]))
+    oracle_y = ob.tjds_spmv(ob.tjds_build(coo, m, n), np.ones(n), refquirks=True)
+    if name in EXACT:
+        assert ob.fmt_g(y) == want
+        assert np.array_equal(y, oracle_y)
+    else:
+        # memplus: atomics reorder the sums; compare normwise and the %g text on well-conditioned rows
+        row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+        scale = row_scale(row_ptr, col_ind, val, np.ones(n))
+        assert_close(y, oracle_y, scale)
+        got = ob.fmt_g(y)
+        well = np.abs(oracle_y) > 1e-6 * scale
+        diff = [i for i in np.flatnonzero(well) if got[i] != want[i]]
+        assert len(diff) <= 0.001 * m
+    # back to the corrected product
+    T.set_ref_quirks(False)
+    T.zero_y(dy)
+    T.spmv(dy)
+    torch.cuda.synchronize()
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    assert_close(dy.cpu().numpy(), ob.csr_spmv(row_ptr, col_ind, val, np.ones(n)),
+                 row_scale(row_ptr, col_ind, val, np.ones(n)))
+    T.close()
+
+
+# ------------------------------------------------------------------- edge cases
+def csr_from_lengths(rng, lens, cols):
+    rows = len(lens)
+    row_ptr = np.zeros(rows + 1, dtype=np.int32)
+    np.cumsum(lens, out=row_ptr[1:])
+    col_ind = np.concatenate([np.sort(rng.choice(cols, size=l, replace=False)) for l in lens] + [np.zeros(0, int)])
+    val = rng.uniform(-1, 1, int(row_ptr[-1]))
+    return row_ptr, col_ind.astype(np.int32), val
+
+
+EDGE_CASES = {
+    "empty_matrix": lambda rng: ([0, 0, 0, 0], 5),
+    "single_entry": lambda rng: ([1], 1),
+    "leading_and_trailing_empty_rows": lambda rng: ([0, 0, 0, 3, 0, 2, 0, 0], 7),
+    "all_rows_empty_but_one": lambda rng: ([0] * 500 + [40] + [0] * 500, 64),
+    "row_spanning_many_tiles": lambda rng: ([3, 5000, 2, 0, 7000, 1], 8192),
+    "row_ending_exactly_on_tile_edges": lambda rng: ([1024, 1024, 2048, 1, 1023], 4096),
+    "many_short_rows": lambda rng: (rng.integers(0, 4, 20000).tolist(), 300),
+    "mixed_skew": lambda rng: (np.where(rng.random(3000) < 0.01, rng.integers(200, 3000, 3000),
+                                        rng.integers(0, 12, 3000)).tolist(), 5000),
+    "wide_rectangular": lambda rng: (rng.integers(0, 50, 100).tolist(), 100000),
+    "tall_rectangular": lambda rng: (rng.integers(0, 3, 50000).tolist(), 3),
+    "exactly_33_per_row": lambda rng: ([33] * 777, 100),
+}
+
+
+@pytest.mark.parametrize("case", sorted(EDGE_CASES))
+@pytest.mark.parametrize("kernel,param", CSR_VARIANTS)
+def test_csr_edge_cases(torch, case, kernel, param):
+    rng = np.random.default_rng(zlib.crc32(case.encode()))
+    lens, cols = EDGE_CASES[case](rng)
+    row_ptr, col_ind, val = csr_from_lengths(rng, lens, cols)
+    rows = len(lens)
+    x = rng.random(cols)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+    y = gpu_csr(torch, rows, cols, row_ptr, col_ind, val, x, kernel, param)
+    assert_close(y, ref, row_scale(row_ptr, col_ind, val, x))
+
+
+@pytest.mark.parametrize("case", sorted(EDGE_CASES))
+def test_tjds_edge_cases(torch, case):
+    rng = np.random.default_rng(zlib.crc32(case.encode()))
+    lens, cols = EDGE_CASES[case](rng)
+    row_ptr, col_ind, val = csr_from_lengths(rng, lens, cols)
+    rows = len(lens)
+    coo = sm.make_coo(np.repeat(np.arange(rows), lens), col_ind, val)
+    coo = coo[rng.permutation(len(coo))]
+    x = rng.random(cols)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+    y, ms, st = sm.tjds_compute(coo, rows, cols, iters=2, x=x)
+    assert_close(y, ref, row_scale(row_ptr, col_ind, val, x))
+    y, ms, st = sm.csr_compute(coo, rows, cols, iters=2, x=x)
+    assert_close(y, ref, row_scale(row_ptr, col_ind, val, x))
+
+
+def test_create_rejects_malformed_arrays(torch):
+    good = (np.array([0, 1, 2], np.int32), np.array([0, 1], np.int32), np.ones(2))
+    sm.CsrMatrix(2, 2, *good).close()
+    with pytest.raises(sm.SmvpError):
+        sm.CsrMatrix(2, 2, np.array([0, 2, 1], np.int32), good[1], good[2])     # decreasing row_ptr
+    with pytest.raises(sm.SmvpError):
+        sm.CsrMatrix(2, 2, good[0], np.array([0, 7], np.int32), good[2])        # column out of range
+    t = sm.tjds_from_coo(sm.make_coo([0, 1], [0, 1], [1.0, 2.0]), 2, 2)
+    t.row_ind = np.array([0, 9], np.int32)
+    with pytest.raises(sm.SmvpError):
+        sm.TjdsMatrix(t)
+
+
+def test_adopted_device_arrays(torch):
+    """SMVP_MEM_DEVICE: arrays that already live in HBM (torch tensors) are used in place."""
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, 20, 5000).tolist()
+    row_ptr, col_ind, val = csr_from_lengths(rng, lens, 4000)
+    x = rng.random(4000)
+    A = sm.CsrMatrix(5000, 4000, dev(torch, row_ptr), dev(torch, col_ind), dev(torch, val))
+    dy = torch.empty(5000, dtype=torch.float64, device="cuda")
+    A.spmv(dev(torch, x), dy)
+    torch.cuda.synchronize()
+    assert_close(dy.cpu().numpy(), ob.csr_spmv(row_ptr, col_ind, val, x), row_scale(row_ptr, col_ind, val, x))
+
+
+def test_runs_on_a_non_default_stream(torch):
+    m, n, coo = load("memplus.mtx")
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    A = sm.CsrMatrix(m, n, row_ptr, col_ind, val)
+    s = torch.cuda.Stream()
+    dx = dev(torch, np.ones(n))
+    dy = torch.zeros(m, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(5):
+        A.spmv(dx, dy, stream=s)
+    s.synchronize()
+    assert_close(dy.cpu().numpy(), ob.csr_spmv(row_ptr, col_ind, val, np.ones(n)),
+                 row_scale(row_ptr, col_ind, val, np.ones(n)))
+
+
+# ------------------------------------------- full-size synthetic: properties only
+@pytest.fixture(scope="module")
+def big(torch):
+    """memplus-shaped synthetic at 2^22 rows (~30 M entries, ~0.44 GB of SpMV traffic)."""
+    M = 1 << 22
+    row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_MEMPLUS_SHAPED, 12345, M, M)
+    return M, row_ptr, col_ind, val
+
+
+def test_big_synthetic_properties(torch, big):
+    M, row_ptr, col_ind, val = big
+    A = sm.CsrMatrix(M, M, row_ptr, col_ind, val)
+    ones = torch.ones(M, dtype=torch.float64, device="cuda")
+    y1 = torch.empty(M, dtype=torch.float64, device="cuda")
+    A.spmv(ones, y1)
+    torch.cuda.synchronize()
+    # (1) x = ones: y is the row sum -- an independent host computation
+    host = np.add.reduceat(val, row_ptr[:-1])
+    scale = np.add.reduceat(np.abs(val), row_ptr[:-1])
+    assert np.all(np.abs(y1.cpu().numpy() - host) <= TOL * scale)
+    # (2) kernel families agree with each other
+    rng = np.random.default_rng(67890)
+    xa, xb = dev(torch, rng.random(M)), dev(torch, rng.random(M))
+    ya, yb, yab, yv = (torch.empty(M, dtype=torch.float64, device="cuda") for _ in range(4))
+    A.spmv(xa, ya)
+    A.spmv(xb, yb)
+    A.spmv(xa + xb, yab)
+    A.set_kernel(sm.CSR_KERNEL_VECTOR, 8)
+    A.spmv(xa, yv)
+    torch.cuda.synchronize()
+    sc = torch.from_numpy(scale).cuda() * 2
+    assert bool(((ya - yv).abs() <= TOL * sc).all())
+    # (3) linearity: A(xa + xb) = A xa + A xb
+    assert bool(((yab - (ya + yb)).abs() <= TOL * sc).all())
+    # (4) a slice of rows against the oracle
+    k = 100_000
+    sub = ob.csr_spmv(row_ptr[:k + 1].copy(), col_ind[:row_ptr[k]], val[:row_ptr[k]], xa.cpu().numpy())
+    assert np.all(np.abs(ya.cpu().numpy()[:k] - sub) <= TOL * 2 * scale[:k])
+    # (5) idempotence: the same launch twice gives the same bits (no atomics on the CSR path)
+    A.set_kernel(sm.CSR_KERNEL_STREAM, 0)
+    y2 = torch.empty_like(ya)
+    A.spmv(xa, y2)
+    torch.cuda.synchronize()
+    assert torch.equal(ya, y2)
+    A.close()
+
+
+def test_big_synthetic_tjds_agrees_with_csr(torch):
+    M = 1 << 20
+    row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_MEMPLUS_SHAPED, 12345, M, M)
+    coo = sm.make_coo(np.repeat(np.arange(M), np.diff(row_ptr)), col_ind, val)
+    x = np.random.default_rng(3).random(M)
+    y_t, _, _ = sm.tjds_compute(coo, M, M, iters=1, x=x)
+    y_c, _, _ = sm.csr_compute(coo, M, M, iters=1, x=x)
+    scale = np.add.reduceat(np.abs(val), row_ptr[:-1])
+    assert np.all(np.abs(y_t - y_c) <= TOL * scale)
+
+
+# ------------------------------------------------------------ entry points + CLI
+@pytest.mark.parametrize("name", SAMPLES)
+def test_reference_shaped_entry_points(torch, name):
+    m, n, coo = load(name)
+    before = coo.tobytes()
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, np.ones(n))
+    scale = row_scale(row_ptr, col_ind, val, np.ones(n))
+    y, ms, st = sm.csr_compute(coo, m, n, iters=20)
+    assert_close(y, ref, scale, exact=name in EXACT)
+    assert len(ms) == 20 and np.all(ms > 0) and st.time_total == pytest.approx(ms.sum())
+    assert st.time_min == ms.min() and st.time_max == ms.max() and st.time_stdev == pytest.approx(ms.std())
+    y, ms, st = sm.tjds_compute(coo, m, n, iters=20)
+    assert_close(y, ref, scale, exact=name in EXACT)
+    assert coo.tobytes() == before
+
+
+@pytest.mark.parametrize("name", ["ibm32.mtx", "curtis54.mtx", "pwt.mtx"])
+def test_cli_all_algs_end_to_end(torch, name, tmp_path):
+    """BASELINE config 1/5 plumbing: --all-algs -n 1000 writes both reports; y blocks equal the committed ones."""
+    path = ob.fixture_path(name)
+    p = subprocess.run([sm.CLI_PATH, "--all-algs", "-n", "1000", "-d", str(tmp_path), path],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    for tag in ("[START]", "Converting loaded content to CSR format.", "Calculating 1000 iterations of SMVP CSR.",
+                "Converting loaded content to TJDS format.", "Calculating 1000 iterations of SMVP TJDS.",
+                "Execution report file saved as:", "[STOP]\tExit smvp-toolbox v0.6.4"):
+        assert tag in p.stdout
+    files = sorted(os.listdir(tmp_path))
+    assert len(files) == 2 and files[0].startswith("smvp-toolbox_report_CSR_") and \
+        files[1].startswith("smvp-toolbox_report_TJDS_")
+    csr_ref = ob.read_report("smvp-toolbox_report_CSR_%s.txt" % REPORTS[name][0])
+    got = open(tmp_path / files[0]).read()
+    assert _mask(got).replace(path, "PATH") == _mask(csr_ref).replace(csr_ref.split("\n")[4], "PATH")
+    # corrected TJDS: y block equals the CSR report's y block
+    got_t = open(tmp_path / files[1]).read()
+    assert ob.report_y_lines(got_t) == ob.report_y_lines(csr_ref)
+    assert "TJDS algorithm" in got_t
+
+
+def test_cli_ref_quirks_reproduces_reference_tjds_report(torch, tmp_path):
+    name = "curtis54.mtx"
+    p = subprocess.run([sm.CLI_PATH, "-t", "--ref-quirks", "-n", "5", "-d", str(tmp_path), ob.fixture_path(name)],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    got = open(tmp_path / os.listdir(tmp_path)[0]).read()
+    want = ob.read_report("smvp-toolbox_report_TJDS_%s.txt" % REPORTS[name][1])
+    assert ob.report_y_lines(got) == ob.report_y_lines(want)

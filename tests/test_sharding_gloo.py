@@ -1,0 +1,78 @@
+"""The N>1 path on CPU: two gloo ranks, row-block sharding + all-gather of y.
+
+The per-rank product is done by the oracle here (no GPU in this container); what is
+under test is the partition, the independent per-block generation and the exchange.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_binding as ob
+import smvp_toolkit_amd as sm
+from smvp_toolkit_amd import sharding
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, case, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if case == "synthetic_equal_rows":
+            M = 40_000
+            bounds = sharding.equal_row_bounds(M, world)
+            r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+            row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_MEMPLUS_SHAPED, 12345, M, M, row_begin=r0, row_end=r1,
+                                                 threads=1)
+            x = np.random.default_rng(0).random(M)
+        else:                       # a real matrix, partition balanced by bytes -> unequal blocks
+            tc, M, N, coo = sm.mm_read_coo(ob.fixture_path("memplus.mtx"))
+            rp, ci, v = sm.csr_from_coo(coo, M)
+            bounds = sm.partition_rows(rp, world).astype(np.int64)
+            r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+            row_ptr, col_ind, val = sharding.slice_csr(rp, ci, v, r0, r1)
+            x = np.ones(N)
+        y_local = torch.from_numpy(ob.csr_spmv(row_ptr, col_ind, val, x))
+        y_full = torch.full((M,), float("nan"), dtype=torch.float64)
+        sharding.allgather_y(dist, y_local, y_full, bounds)
+        if rank == 0:
+            np.save(out, y_full.numpy())
+        # every rank must hold the same full vector
+        ref = y_full.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(ref, y_full)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["synthetic_equal_rows", "memplus_byte_balanced"])
+def test_two_rank_row_block_spmv(case, tmp_path):
+    out = str(tmp_path / "y.npy")
+    mp.spawn(_worker, args=(2, _free_port(), case, out), nprocs=2, join=True)
+    y = np.load(out)
+    if case == "synthetic_equal_rows":
+        M = 40_000
+        row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_MEMPLUS_SHAPED, 12345, M, M, threads=1)
+        x = np.random.default_rng(0).random(M)
+    else:
+        tc, M, N, coo = sm.mm_read_coo(ob.fixture_path("memplus.mtx"))
+        row_ptr, col_ind, val = sm.csr_from_coo(coo, M)
+        x = np.ones(N)
+    assert np.array_equal(y, ob.csr_spmv(row_ptr, col_ind, val, x))
+
+
+def test_bounds_helpers():
+    b = sharding.equal_row_bounds(10, 4)
+    assert b.tolist() == [0, 2, 5, 7, 10]
+    counts, pad = sharding.gather_counts(b)
+    assert counts.tolist() == [2, 3, 2, 3] and pad == 3
+    assert sharding.equal_row_bounds(1 << 24, 8).tolist() == [(1 << 21) * g for g in range(9)]
