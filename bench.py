@@ -5,12 +5,25 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one product y = A x over the whole (sharded) matrix, inputs resident in
-HBM.  Default workload: the memplus-shaped synthetic of SURVEY 8(d) at 2^24 rows
-(~119 M entries, ~1.8 GB of algorithmic traffic -- memplus.mtx itself is 1.9 MB and
-lives in L2, so it says nothing about HBM), CSR, x = ones like the reference
-(main-cli.c:368-369).  With N > 1 the fixed matrix is cut into N row blocks, one
-process per GPU, and a step is the local product plus the RCCL all-gather of the y
-blocks over xGMI (strong scaling).
+HBM, CSR, x = ones like the reference (main-cli.c:368-369).  memplus.mtx itself is
+1.9 MB and lives in L2, so it says nothing about HBM; the workloads are HBM-sized
+matrices with memplus's shape (DESIGN.md "Workloads" has the reasoning):
+
+  memplus_tiled   (default) memplus.mtx replicated 944x along the diagonal,
+                  kron(I_944, memplus): 16.76 M rows, 119 M entries, 1.77 GB of
+                  algorithmic traffic.  Every structural property of memplus is kept
+                  exactly (row lengths, symmetry, its 165 hub rows/columns, all entries
+                  within 17757 of the diagonal) and y is checkable at full size against
+                  the reference's own committed memplus report.
+  memplus_shaped  the random model of SURVEY 8(d): memplus's row-length histogram
+                  and band profile, entries beyond distance 4096 uniform over ALL 2^24
+                  columns.  Always measured too (extra.survey_random_model): it is bound
+                  by the chip's random-gather rate, not by HBM.
+  uniform32       BASELINE config 4: 10 M x 10 M, 32 uniform entries per row.
+
+With N > 1 the fixed matrix is cut into N row blocks, one process per GPU, and a
+step is the local product plus the RCCL all-gather of the y blocks over xGMI
+(strong scaling).
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM
 (algorithmic bytes of SURVEY 8(d) / measured time per launch); `cpu_baseline` is the
@@ -27,8 +40,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "smvp-toolkit_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+TOL = 1e-9              # row-normwise: |dy| <= TOL * sum_j |a_rj x_j|
 
 
 def parse():
@@ -36,13 +51,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="memplus_shaped", choices=["memplus_shaped", "uniform32"])
+    ap.add_argument("--workload", default="memplus_tiled", choices=["memplus_tiled", "memplus_shaped", "uniform32"])
+    ap.add_argument("--copies", type=int, default=944, help="memplus_tiled: diagonal blocks (944 -> 16.76 M rows)")
     ap.add_argument("--rows-log2", type=int, default=24, help="memplus_shaped: total rows = 2^k")
     ap.add_argument("--rows", type=int, default=10_000_000, help="uniform32: total rows (BASELINE config 4)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "vector"])
     ap.add_argument("--kernel-param", type=int, default=0)
     ap.add_argument("--x", default="ones", choices=["ones", "random"])
     ap.add_argument("--no-tjds", action="store_true", help="skip the TJDS leg (extra.tjds)")
+    ap.add_argument("--no-random-model", action="store_true", help="skip extra.survey_random_model")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0, help="0 = sized for about 15 s")
     ap.add_argument("--no-allgather", action="store_true", help="N > 1: time the local products only")
@@ -55,7 +72,7 @@ def log(rank, *a):
 
 
 def timed_region(torch, dist, world, steps, body):
-    """barrier + sync, `steps` x body(), sync + barrier; returns (wall seconds max over ranks, event ms)."""
+    """barrier + sync, `steps` x body(), sync + barrier -> (wall seconds, HIP-event ms), both MAX over ranks."""
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -75,6 +92,132 @@ def timed_region(torch, dist, world, steps, body):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(t[0]), float(t[1])
     return wall, ev_ms
+
+
+def build_block(sm, sharding, workload, args, rank, world):
+    """This rank's row block of the workload -> dict with host CSR arrays and a description."""
+    t0 = time.perf_counter()
+    if workload == "memplus_tiled":
+        import oracle_binding as ob           # fixture lookup only (tests/golden/sample-data/memplus.mtx.gz)
+
+        tc, m, n, coo = sm.mm_read_coo(ob.fixture_path("memplus.mtx"))
+        rp, ci, v = sm.csr_from_coo(coo, m)
+        copies = args.copies - args.copies % world if args.copies >= world else world
+        c0, c1 = copies * rank // world, copies * (rank + 1) // world
+        row_ptr, col_ind, val = sharding.tile_block_diagonal(rp, ci, v, n, c0, c1)
+        blk = dict(rows_total=m * copies, cols_total=n * copies, r0=m * c0, r1=m * c1,
+                   name="memplus.mtx x%d block-diagonal (kron(I_%d, memplus))" % (copies, copies),
+                   base=(m, n, rp, ci, v, c1 - c0))
+    else:
+        if workload == "memplus_shaped":
+            kind, seed, param = sm.SYNTH_MEMPLUS_SHAPED, 12345, 0
+            rows_total = cols_total = 1 << args.rows_log2
+            name = "memplus_shaped random model (SURVEY 8(d)) rows=2^%d seed=%d" % (args.rows_log2, seed)
+        else:
+            kind, seed, param = sm.SYNTH_UNIFORM, 2024, 32
+            rows_total = cols_total = args.rows
+            name = "uniform 32 entries/row rows=%d seed=%d" % (rows_total, seed)
+        bounds = sharding.equal_row_bounds(rows_total, world)
+        r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+        row_ptr, col_ind, val = sm.synth_csr(kind, seed, rows_total, cols_total, param, r0, r1,
+                                             threads=max(1, min(16, (os.cpu_count() or 8) // max(1, world))))
+        blk = dict(rows_total=rows_total, cols_total=cols_total, r0=r0, r1=r1, name=name, base=None)
+    blk.update(row_ptr=row_ptr, col_ind=col_ind, val=val, nnz=int(row_ptr[-1]), rows=blk["r1"] - blk["r0"])
+    log(rank, "%s: rows [%d, %d), %d entries, built in %.1f s" % (blk["name"], blk["r0"], blk["r1"], blk["nnz"],
+                                                                  time.perf_counter() - t0))
+    return blk
+
+
+def host_check(blk, x_host, got):
+    """Independent host computation of this block's y (numpy, not the oracle); returns (ok, worst, scale)."""
+    row_ptr, col_ind, val = blk["row_ptr"], blk["col_ind"], blk["val"]
+    nonempty = np.diff(row_ptr) > 0
+    prod = val * x_host[col_ind]
+    starts = np.minimum(row_ptr[:-1], max(len(prod) - 1, 0))
+    host = np.add.reduceat(prod, starts) * nonempty if len(prod) else np.zeros(blk["rows"])
+    scale = np.add.reduceat(np.abs(prod), starts) * nonempty if len(prod) else np.zeros(blk["rows"])
+    err = np.abs(got - host)
+    return bool(np.all(err <= TOL * scale)), float((err / np.maximum(scale, 1e-300)).max()), scale
+
+
+def measure_csr(torch, dist, sm, blk, args, world, local_rank, rank, steps, warmup, collective):
+    """Upload the block, check it, time `steps` products (+ all-gather), then the kernel alone."""
+    d_row_ptr = torch.from_numpy(blk["row_ptr"]).cuda()
+    d_col_ind = torch.from_numpy(blk["col_ind"]).cuda()
+    d_val = torch.from_numpy(blk["val"]).cuda()
+    A = sm.CsrMatrix(blk["rows"], blk["cols_total"], d_row_ptr, d_col_ind, d_val, device=local_rank)
+    if args.kernel != "auto" or args.kernel_param:
+        A.set_kernel({"auto": 0, "vector": 1, "stream": 2}[args.kernel], args.kernel_param)
+    kernel_name, alg_bytes = A.describe()
+
+    x_host = np.ones(blk["cols_total"]) if args.x == "ones" else np.random.default_rng(67890).random(blk["cols_total"])
+    d_x = torch.from_numpy(x_host).cuda()
+    d_y_full = torch.zeros(blk["rows_total"], dtype=torch.float64, device="cuda")
+    d_y = d_y_full[blk["r0"]:blk["r1"]]
+    stream = torch.cuda.current_stream()
+    gather = collective and world > 1
+
+    def spmv_only():
+        A.spmv(d_x, d_y, stream=stream)
+
+    def step():
+        A.spmv(d_x, d_y, stream=stream)
+        if gather:
+            dist.all_gather_into_tensor(d_y_full, d_y)
+
+    # correctness gate before any timing
+    step()
+    torch.cuda.synchronize()
+    got = d_y.cpu().numpy()
+    ok, worst, scale = host_check(blk, x_host, got)
+    if not ok:
+        raise SystemExit("rank %d: product is wrong on %s (max normwise error %g)" % (rank, blk["name"], worst))
+    golden = None
+    if blk["base"] is not None and args.x == "ones":
+        # full-size parity against the reference's own golden vector: y = tile(y_memplus), whose "%g" text is the
+        # committed report output-test/smvp-toolbox_report_CSR_1615284663.txt
+        import oracle_binding as ob
+
+        m, n, rp, ci, v, ncopies = blk["base"]
+        y_base = ob.csr_spmv(rp, ci, v, np.ones(n))
+        report_ok = ob.fmt_g(y_base) == ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_1615284663.txt"))
+        sc = ob.csr_spmv(rp, ci, np.abs(v), np.ones(n))
+        tiles_ok = bool(np.all(np.abs(got.reshape(ncopies, m) - y_base[None, :]) <= TOL * sc[None, :]))
+        bit_identical = float((got.reshape(ncopies, m) == y_base[None, :]).mean())
+        if not (report_ok and tiles_ok):
+            raise SystemExit("rank %d: y is not tile(y_memplus)" % rank)
+        golden = {"y_equals_tiled_reference_memplus_y": True, "rows_bit_identical_to_serial": round(bit_identical, 4)}
+    if gather:
+        chk = float(d_y_full.sum().item())
+        t = torch.tensor([chk, -chk], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if float(t[0]) != -float(t[1]):
+            raise SystemExit("all-gathered y differs between ranks")
+    log(rank, "correct: max |dy| / sum|a x| = %.2e over %d local rows (%s)" % (worst, blk["rows"], kernel_name))
+
+    for _ in range(warmup):
+        step()
+    wall, _ = timed_region(torch, dist, world, steps, step)
+    for _ in range(3):
+        spmv_only()
+    _, k_ms = timed_region(torch, dist, world, steps, spmv_only)   # HIP events on the launch stream, no collective
+
+    tot = torch.tensor([blk["nnz"], alg_bytes], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tot)
+    res = dict(kernel=kernel_name, alg_bytes_local=alg_bytes, alg_bytes_total=float(tot[1]), nnz_total=float(tot[0]),
+               wall_per_step=wall / steps, kernel_ms=k_ms / steps, worst=worst, golden=golden, scale=scale, got=got,
+               x_host=x_host, d_x=d_x, d_y=d_y, A=A, keep=(d_row_ptr, d_col_ind, d_val, d_y_full))
+    return res
+
+
+def roofline_of(res):
+    achieved = res["alg_bytes_local"] / (res["kernel_ms"] * 1e-3) * 1e-9
+    return {"bound": "hbm", "kernel": res["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "alg_bytes_per_launch": res["alg_bytes_local"], "ms_per_launch": round(res["kernel_ms"], 5),
+            "note": "per launch = CSR kernel + its 5 us carry fix-up, HIP events on the launch stream; "
+                    "traffic (PMC FETCH_SIZE/WRITE_SIZE) is in profiles/"}
 
 
 def main():
@@ -101,110 +244,38 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev_name, cus, hbm = sm.device_info(local_rank)
 
-    # ------------------------------------------------------------ the workload
-    if args.workload == "memplus_shaped":
-        kind, seed, param = sm.SYNTH_MEMPLUS_SHAPED, 12345, 0
-        rows_total = cols_total = 1 << args.rows_log2
-        wl_name = "memplus_shaped_synthetic rows=2^%d seed=%d" % (args.rows_log2, seed)
-    else:
-        kind, seed, param = sm.SYNTH_UNIFORM, 2024, 32
-        rows_total = cols_total = args.rows
-        wl_name = "uniform32_synthetic rows=%d seed=%d" % (rows_total, seed)
-    bounds = sharding.equal_row_bounds(rows_total, world)
-    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
-    t_gen = time.perf_counter()
-    row_ptr, col_ind, val = sm.synth_csr(kind, seed, rows_total, cols_total, param, r0, r1,
-                                         threads=max(1, min(16, (os.cpu_count() or 8) // max(1, world))))
-    rows_local, nnz_local = r1 - r0, int(row_ptr[-1])
-    log(rank, "generated rows [%d, %d): %d entries in %.1f s" % (r0, r1, nnz_local, time.perf_counter() - t_gen))
-
-    d_row_ptr = torch.from_numpy(row_ptr).cuda()
-    d_col_ind = torch.from_numpy(col_ind).cuda()
-    d_val = torch.from_numpy(val).cuda()
-    A = sm.CsrMatrix(rows_local, cols_total, d_row_ptr, d_col_ind, d_val, device=local_rank)
-    if args.kernel != "auto" or args.kernel_param:
-        A.set_kernel({"auto": 0, "vector": 1, "stream": 2}[args.kernel], args.kernel_param)
-    kernel_name, alg_bytes_local = A.describe()
-
-    if args.x == "ones":
-        x_host = np.ones(cols_total)
-    else:
-        x_host = np.random.default_rng(67890).random(cols_total)
-    d_x = torch.from_numpy(x_host).cuda()
-    d_y_full = torch.zeros(rows_total, dtype=torch.float64, device="cuda")
-    d_y = d_y_full[r0:r1] if world > 1 else d_y_full
-    stream = torch.cuda.current_stream()
-
-    def spmv_only():
-        A.spmv(d_x, d_y, stream=stream)
-
-    def step():
-        A.spmv(d_x, d_y, stream=stream)
-        if world > 1 and not args.no_allgather:
-            dist.all_gather_into_tensor(d_y_full, d_y)
-
-    # correctness gate before any timing: an independent host computation of this block
-    step()
-    torch.cuda.synchronize()
-    host = np.add.reduceat(val * x_host[col_ind], row_ptr[:-1]) * (np.diff(row_ptr) > 0)
-    scale = np.add.reduceat(np.abs(val * x_host[col_ind]), row_ptr[:-1]) * (np.diff(row_ptr) > 0)
-    got = d_y_full[r0:r1].cpu().numpy()
-    worst = float((np.abs(got - host) / np.maximum(scale, 1e-300)).max())
-    if not np.all(np.abs(got - host) <= 1e-9 * scale):
-        raise SystemExit("rank %d: product is wrong (max normwise error %g)" % (rank, worst))
-    if world > 1 and not args.no_allgather:
-        chk = d_y_full.sum().item()      # every rank must hold the same gathered vector
-        t = torch.tensor([chk, -chk], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        if float(t[0]) != -float(t[1]):
-            raise SystemExit("all-gathered y differs between ranks")
-    log(rank, "correct: max |dy| / sum|a x| = %.2e over %d local rows (%s)" % (worst, rows_local, kernel_name))
-
-    # ------------------------------------------------------------ the timed run
-    for _ in range(args.warmup):
-        step()
-    wall, ev_ms = timed_region(torch, dist, world, args.steps, step)
-    ms_per_step = wall * 1e3 / args.steps
-
-    t_nnz = torch.tensor([nnz_local, alg_bytes_local], dtype=torch.float64, device="cuda")
+    # ------------------------------------------------------------ headline: CSR on the workload
+    blk = build_block(sm, sharding, args.workload, args, rank, world)
+    res = measure_csr(torch, dist, sm, blk, args, world, local_rank, rank, args.steps, args.warmup,
+                      collective=not args.no_allgather)
+    gflops = 2.0 * res["nnz_total"] / res["wall_per_step"] * 1e-9
+    extra = {"device": dev_name, "compute_units": cus, "nnz": int(res["nnz_total"]), "rows": blk["rows_total"],
+             "alg_bytes_per_step": res["alg_bytes_total"], "x": args.x,
+             "whole_job_GBps": round(res["alg_bytes_total"] / res["wall_per_step"] * 1e-9, 1),
+             "max_normwise_error_vs_host": res["worst"]}
+    if res["golden"]:
+        extra["full_size_parity"] = res["golden"]
     if world > 1:
-        dist.all_reduce(t_nnz)
-    nnz_total, alg_bytes_total = float(t_nnz[0]), float(t_nnz[1])
-    gflops = 2.0 * nnz_total / (wall / args.steps) * 1e-9
-
-    # dominant kernel alone (no collective in the window), HIP events on the launch stream
-    for _ in range(3):
-        spmv_only()
-    _, k_ms = timed_region(torch, dist, world, args.steps, spmv_only)
-    k_ms_per_launch = k_ms / args.steps
-    achieved = alg_bytes_local / (k_ms_per_launch * 1e-3) * 1e-9          # GB/s, this rank's kernel
-    roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "alg_bytes_per_launch": alg_bytes_local, "ms_per_launch": round(k_ms_per_launch, 5),
-                "note": "per launch = csr kernel + its carry fix-up; traffic: see profiles/ (PMC pass)"}
-
-    extra = {"device": dev_name, "compute_units": cus, "nnz": int(nnz_total), "rows": rows_total,
-             "alg_bytes_per_step": alg_bytes_total, "x": args.x,
-             "whole_job_GBps": round(alg_bytes_total / (wall / args.steps) * 1e-9, 1)}
-    if world > 1:
-        extra["spmv_only_GFLOPs_per_rank_max_time"] = round(2.0 * nnz_total / (k_ms_per_launch * 1e-3) * 1e-9, 1)
+        extra["spmv_only_ms"] = round(res["kernel_ms"], 5)
+        extra["spmv_only_GFLOPs"] = round(2.0 * res["nnz_total"] / (res["kernel_ms"] * 1e-3) * 1e-9, 1)
         extra["allgather_in_step"] = not args.no_allgather
-        extra["y_bytes_gathered"] = rows_total * 8
+        extra["y_bytes_gathered"] = blk["rows_total"] * 8
 
-    # ------------------------------------------------------------ TJDS beside it
+    # ------------------------------------------------------------ TJDS beside it (same matrix)
     if not args.no_tjds and world == 1:
         try:
             t0 = time.perf_counter()
-            coo = np.zeros(nnz_local, dtype=sm.COO_DTYPE)
-            coo["row"] = np.repeat(np.arange(rows_local, dtype=np.int32), np.diff(row_ptr))
-            coo["col"], coo["val"] = col_ind, val
-            tj = sm.tjds_from_coo(coo, rows_local, cols_total)
+            coo = np.zeros(blk["nnz"], dtype=sm.COO_DTYPE)
+            coo["row"] = np.repeat(np.arange(blk["rows"], dtype=np.int32), np.diff(blk["row_ptr"]))
+            coo["col"], coo["val"] = blk["col_ind"], blk["val"]
+            tj = sm.tjds_from_coo(coo, blk["rows"], blk["cols_total"])
             del coo
             T = sm.TjdsMatrix(tj, device=local_rank)
             tname, tbytes = T.describe()
             log(rank, "TJDS built in %.1f s: %d jagged diagonals" % (time.perf_counter() - t0, tj.num_diag))
-            d_yt = torch.empty(rows_local, dtype=torch.float64, device="cuda")
-            T.set_x(d_x, stream=stream)
+            stream = torch.cuda.current_stream()
+            d_yt = torch.empty(blk["rows"], dtype=torch.float64, device="cuda")
+            T.set_x(res["d_x"], stream=stream)
 
             def tjds_step():
                 T.zero_y(d_yt, stream=stream)       # the scatter needs y = 0 (main-cli.c:1008); counted in the step
@@ -212,56 +283,81 @@ def main():
 
             tjds_step()
             torch.cuda.synchronize()
-            terr = float(((d_yt - d_y).abs().cpu().numpy() / np.maximum(scale, 1e-300)).max())
+            terr = float((np.abs(d_yt.cpu().numpy() - res["got"]) / np.maximum(res["scale"], 1e-300)).max())
+            if terr > TOL:
+                raise RuntimeError("TJDS differs from CSR: %g" % terr)
             tsteps = max(5, args.steps // 10)
             _, t_ms = timed_region(torch, dist, 1, tsteps, tjds_step)
             t_ms /= tsteps
             extra["tjds"] = {"kernel": tname, "ms_per_step": round(t_ms, 4), "num_diag": tj.num_diag,
-                             "GFLOPs": round(2.0 * nnz_local / (t_ms * 1e-3) * 1e-9, 1),
+                             "GFLOPs": round(2.0 * blk["nnz"] / (t_ms * 1e-3) * 1e-9, 1),
                              "achieved_GBps": round(tbytes / (t_ms * 1e-3) * 1e-9, 1),
                              "frac_of_hbm_peak": round(tbytes / (t_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4),
                              "max_normwise_diff_vs_csr": terr, "steps": tsteps,
-                             "note": "step = memset(y) + scatter kernel (fp64 atomics)"}
+                             "note": "step = memset(y) + column-major scatter kernel (fp64 atomics)"}
             T.close()
+            del T, tj, d_yt
         except Exception as e:  # the TJDS leg is informational; never lose the headline line over it
             extra["tjds"] = {"error": str(e)}
 
-    # ------------------------------------------------------------ CPU baseline
+    # ------------------------------------------------------------ CPU baseline (rank 0, N = 1)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_binding as ob          # the checker, used here only as the CPU baseline leg
 
-        _, probe = ob.csr_timed(row_ptr, col_ind, val, x_host, 1)
-        iters = args.cpu_iters or int(max(2, min(50, round(15000.0 / max(probe[0], 1e-3)))))
-        y_cpu, ms = ob.csr_timed(row_ptr, col_ind, val, x_host, iters)
-        cpu_ok = bool(np.all(np.abs(y_cpu - got) <= 1e-9 * scale))
+        rp, ci, v, xh = blk["row_ptr"], blk["col_ind"], blk["val"], res["x_host"]
+        _, probe = ob.csr_timed(rp, ci, v, xh, 1)
+        iters = args.cpu_iters or int(max(2, min(100, round(15000.0 / max(probe[0], 1e-3)))))
+        y_cpu, ms = ob.csr_timed(rp, ci, v, xh, iters)
         model = ""
         try:
             model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
         except Exception:
             pass
-        cpu = {"value": round(2.0 * nnz_local / (ms.mean() * 1e-3) * 1e-9, 3), "unit": "GFLOP/s", "cores": 1,
+        cpu = {"value": round(2.0 * blk["nnz"] / (ms.mean() * 1e-3) * 1e-9, 3), "unit": "GFLOP/s", "cores": 1,
                "kind": "port", "host_cores_total": os.cpu_count(), "host_cpu": model,
-               "GBps": round(alg_bytes_local / (ms.mean() * 1e-3) * 1e-9, 2), "ms_per_product": round(float(ms.mean()), 2),
+               "GBps": round(res["alg_bytes_local"] / (ms.mean() * 1e-3) * 1e-9, 2),
+               "ms_per_product": round(float(ms.mean()), 2),
                "sample": "the full workload matrix, %d products of the serial loop (oracle restatement of "
-                         "main-cli.c:410-416, gcc -O3, y reset outside the window)" % iters,
-               "agrees_with_gpu": cpu_ok}
+                         "main-cli.c:410-416, gcc -O3 -DNDEBUG, y reset outside the window)" % iters,
+               "agrees_with_gpu": bool(np.all(np.abs(y_cpu - res["got"]) <= TOL * res["scale"]))}
+
+    headline_roofline = roofline_of(res)
+    res["A"].close()
+    del res["keep"], res["d_x"], res["d_y"]
+    torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------ the survey's random model, for the record
+    if args.workload == "memplus_tiled" and not args.no_random_model and world == 1:
+        try:
+            blk2 = build_block(sm, sharding, "memplus_shaped", args, rank, world)
+            r2 = measure_csr(torch, dist, sm, blk2, args, world, local_rank, rank, max(10, args.steps // 4), 3, False)
+            rl = roofline_of(r2)
+            far = float((np.abs(np.repeat(np.arange(blk2["rows"]), np.diff(blk2["row_ptr"])) - blk2["col_ind"]) > 4096).mean())
+            extra["survey_random_model"] = {
+                "workload": blk2["name"], "nnz": blk2["nnz"], "kernel": rl["kernel"], "ms_per_launch": rl["ms_per_launch"],
+                "GFLOPs": round(2.0 * blk2["nnz"] / (r2["kernel_ms"] * 1e-3) * 1e-9, 1),
+                "achieved_GBps": rl["achieved"], "frac_of_hbm_peak": rl["frac"],
+                "share_of_entries_beyond_4096": round(far, 3),
+                "note": "uniformly random far columns: bound by the measured L2-miss gather rate (~54 G gathers/s, "
+                        "tools/gather_bench.hip), not by HBM bytes"}
+            r2["A"].close()
+        except Exception as e:
+            extra["survey_random_model"] = {"error": str(e)}
 
     if rank == 0:
         line = {
             "metric": "fp64 CSR SpMV GFLOP/s (2*nnz flop per product; achieved HBM GB/s in roofline)",
             "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(res["wall_per_step"] * 1e3, 5), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wl_name + ", CSR, x=%s" % args.x +
+            "config": {"workload": blk["name"] + ", CSR, x=%s" % args.x +
                        (", %d row blocks + RCCL all-gather of y" % world if world > 1 and not args.no_allgather else ""),
-                       "format": "csr", "kernel": kernel_name, "nnz": int(nnz_total), "rows": rows_total,
-                       "sharding": "row-block x%d" % world},
-            "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
+                       "format": "csr", "kernel": res["kernel"], "nnz": int(res["nnz_total"]),
+                       "rows": blk["rows_total"], "sharding": "row-block x%d" % world},
+            "roofline": headline_roofline, "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(line), flush=True)
-    A.close()
     if world > 1:
         dist.destroy_process_group()
 

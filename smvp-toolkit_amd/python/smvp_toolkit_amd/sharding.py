@@ -52,3 +52,22 @@ def slice_csr(row_ptr, col_ind, val, r0, r1):
     """Rows [r0, r1) of a host CSR matrix with row_ptr rebased to 0."""
     a, b = int(row_ptr[r0]), int(row_ptr[r1])
     return (row_ptr[r0:r1 + 1] - row_ptr[r0]).astype(np.int32), col_ind[a:b], val[a:b]
+
+
+def tile_block_diagonal(row_ptr, col_ind, val, cols, copy_begin, copy_end):
+    """Rows of copies [copy_begin, copy_end) of kron(I_k, A): local row numbering, GLOBAL column numbering.
+
+    Copy c holds A at rows [c*rows, (c+1)*rows) and columns [c*cols, (c+1)*cols); a rank that owns a run of
+    copies therefore needs nothing from the others (row-block sharding at copy granularity).
+    """
+    n = copy_end - copy_begin
+    nnz = int(row_ptr[-1])
+    rp = (row_ptr[:-1][None, :].astype(np.int64) + (np.arange(n, dtype=np.int64) * nnz)[:, None]).reshape(-1)
+    rp = np.concatenate([rp, [n * nnz]])
+    if rp[-1] >= 2 ** 31:
+        raise ValueError("block of %d copies holds %d entries: beyond 32-bit indices" % (n, rp[-1]))
+    ci = (col_ind[None, :].astype(np.int64) +
+          (np.arange(copy_begin, copy_end, dtype=np.int64) * cols)[:, None]).reshape(-1)
+    if len(ci) and ci.max() >= 2 ** 31:
+        raise ValueError("column index beyond 32 bits")
+    return rp.astype(np.int32), ci.astype(np.int32), np.tile(val, n)
