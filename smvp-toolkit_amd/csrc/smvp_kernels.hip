@@ -98,8 +98,12 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_tiles(
     const int e = (int)(s + TILE < (long long)nnz ? s + TILE : (long long)nnz);
     if (t == 0)
         long_count = 0;
+    const int rlo = tile_row[b];
+    const int rhi = tile_row[b + 1];
 
-    // ---- phase 1: stream + gather + multiply
+    // ---- phase 1: stream + gather + multiply.  The full-tile path is straight-line code so that
+    // all VPT gathers of a lane are in flight together; a guarded version that branched per entry
+    // ran 12-25 % slower (MI355X, memplus x944).
     const long long j0 = s + (long long)t * VPT;
     double p[VPT];
     if (j0 + VPT <= (long long)nnz) {
@@ -125,8 +129,6 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_tiles(
     __syncthreads();
 
     // ---- phase 2a: the head of the tile continues an earlier row
-    const int rlo = tile_row[b];
-    const int rhi = tile_row[b + 1];
     const int lo = (int)s;  // nnz < 2^31
     if (t < 64) {
         const int first = rlo < rows ? row_ptr[rlo] : nnz;
@@ -270,15 +272,15 @@ hipError_t launch_csr_stream(int vpt, const int *row_ptr, const int *col_ind, co
     if (rows <= 0)
         return hipSuccess;
     const int tiles_per_xcd = (ntiles + 7) / 8;
-    const unsigned grid = (unsigned)tiles_per_xcd * 8u;
+    const dim3 grid((unsigned)tiles_per_xcd * 8u);
     switch (vpt) {
     case 4:
-        hipLaunchKernelGGL(csr_stream_tiles<4>, dim3(grid), dim3(kStreamBlock), 0, stream, row_ptr, col_ind, val,
-                           x, y, tile_row, carry, rows, nnz, ntiles, tiles_per_xcd);
+        hipLaunchKernelGGL(csr_stream_tiles<4>, grid, dim3(kStreamBlock), 0, stream, row_ptr, col_ind, val, x, y,
+                           tile_row, carry, rows, nnz, ntiles, tiles_per_xcd);
         break;
     case 8:
-        hipLaunchKernelGGL(csr_stream_tiles<8>, dim3(grid), dim3(kStreamBlock), 0, stream, row_ptr, col_ind, val,
-                           x, y, tile_row, carry, rows, nnz, ntiles, tiles_per_xcd);
+        hipLaunchKernelGGL(csr_stream_tiles<8>, grid, dim3(kStreamBlock), 0, stream, row_ptr, col_ind, val, x, y,
+                           tile_row, carry, rows, nnz, ntiles, tiles_per_xcd);
         break;
     default:
         return hipErrorInvalidValue;
