@@ -1,0 +1,42 @@
+#!/bin/bash
+# tools/profile_bench.sh TAG  -- run on the GPU box (through gpurun): per-kernel times and HBM traffic of bench.py's
+# headline workload.  Writes gpurun_out/profile_TAG/{kernel_stats.csv, pmc_summary.txt, traffic.json, bench.json}.
+#   1. rocprofv3 --kernel-trace --stats on `bench.py --no-random-model --no-tjds --no-cpu-baseline`
+#   2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, TCC, SQ ...) on the same command, fewer steps
+# FETCH_SIZE is doubled (gfx950 tallies 128-B reads at 64 B, MI355X_MICROARCH.md "HBM"); WRITE_SIZE is exact.
+set -u
+TAG=${1:-r01}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/profile_$TAG
+mkdir -p "$OUT"
+ARGS="--no-random-model --no-tjds --no-cpu-baseline ${BENCH_ARGS:-}"
+python3 $R/bench.py --steps 100 --warmup 10 $ARGS > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "bench failed"; tail -5 "$OUT/bench.err"; exit 1; }
+cd /tmp; export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 $R/bench.py --steps 100 --warmup 10 $ARGS > "$OUT/trace.log" 2>&1 || echo "kernel-trace pass failed"
+cp "$OUT/trace/t_kernel_stats.csv" "$OUT/kernel_stats.csv" 2>/dev/null
+cd $R
+bash tools/pmc_passes.sh gpurun_out/profile_$TAG/pmc -- python3 $R/bench.py --steps 10 --warmup 2 $ARGS > /dev/null
+python3 tools/pmc_summary.py "$OUT/pmc" csr_stream_tiles > "$OUT/pmc_summary.txt"
+python3 - "$OUT" <<'PY'
+import json, re, sys
+out = sys.argv[1]
+vals = {}
+for line in open(out + "/pmc_summary.txt"):
+    m = re.match(r"(\S+)\s+mean\s+([\d.]+)", line)
+    if m:
+        vals[m.group(1)] = float(m.group(2))
+bench = json.loads(open(out + "/bench.json").read().strip().splitlines()[-1])
+fetch, write = vals.get("FETCH_SIZE"), vals.get("WRITE_SIZE")
+t = {"workload": bench["config"]["workload"], "kernel": bench["roofline"]["kernel"],
+     "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
+     "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024.0 if fetch and write else None,
+     "alg_bytes_per_launch": bench["roofline"]["alg_bytes_per_launch"],
+     "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B read requests at 64 B), WRITE_SIZE as read",
+     "counters": vals}
+if t["traffic_bytes_per_launch"]:
+    t["traffic_over_algorithmic"] = t["traffic_bytes_per_launch"] / t["alg_bytes_per_launch"]
+json.dump(t, open(out + "/traffic.json", "w"), indent=1)
+print(json.dumps({k: t[k] for k in ("traffic_bytes_per_launch", "alg_bytes_per_launch", "traffic_over_algorithmic") if k in t}))
+PY
+cut -c1-150 "$OUT/kernel_stats.csv" | head -6
+cat "$OUT/bench.json" | cut -c1-700
