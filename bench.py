@@ -106,6 +106,7 @@ def build_block(sm, sharding, workload, args, rank, world):
         c0, c1 = copies * rank // world, copies * (rank + 1) // world
         row_ptr, col_ind, val = sharding.tile_block_diagonal(rp, ci, v, n, c0, c1)
         blk = dict(rows_total=m * copies, cols_total=n * copies, r0=m * c0, r1=m * c1,
+                   bounds=np.array([m * (copies * g // world) for g in range(world + 1)], dtype=np.int64),
                    name="memplus.mtx x%d block-diagonal (kron(I_%d, memplus))" % (copies, copies),
                    base=(m, n, rp, ci, v, c1 - c0))
     else:
@@ -121,7 +122,7 @@ def build_block(sm, sharding, workload, args, rank, world):
         r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
         row_ptr, col_ind, val = sm.synth_csr(kind, seed, rows_total, cols_total, param, r0, r1,
                                              threads=max(1, min(16, (os.cpu_count() or 8) // max(1, world))))
-        blk = dict(rows_total=rows_total, cols_total=cols_total, r0=r0, r1=r1, name=name, base=None)
+        blk = dict(rows_total=rows_total, cols_total=cols_total, r0=r0, r1=r1, name=name, base=None, bounds=bounds)
     blk.update(row_ptr=row_ptr, col_ind=col_ind, val=val, nnz=int(row_ptr[-1]), rows=blk["r1"] - blk["r0"])
     log(rank, "%s: rows [%d, %d), %d entries, built in %.1f s" % (blk["name"], blk["r0"], blk["r1"], blk["nnz"],
                                                                   time.perf_counter() - t0))
@@ -140,7 +141,7 @@ def host_check(blk, x_host, got):
     return bool(np.all(err <= TOL * scale)), float((err / np.maximum(scale, 1e-300)).max()), scale
 
 
-def measure_csr(torch, dist, sm, blk, args, world, local_rank, rank, steps, warmup, collective):
+def measure_csr(torch, dist, sm, sharding_mod, blk, args, world, local_rank, rank, steps, warmup, collective):
     """Upload the block, check it, time `steps` products (+ all-gather), then the kernel alone."""
     d_row_ptr = torch.from_numpy(blk["row_ptr"]).cuda()
     d_col_ind = torch.from_numpy(blk["col_ind"]).cuda()
@@ -160,10 +161,12 @@ def measure_csr(torch, dist, sm, blk, args, world, local_rank, rank, steps, warm
     def spmv_only():
         A.spmv(d_x, d_y, stream=stream)
 
+    bounds = blk["bounds"]
+
     def step():
         A.spmv(d_x, d_y, stream=stream)
-        if gather:
-            dist.all_gather_into_tensor(d_y_full, d_y)
+        if gather:      # equal row blocks: gathered in place into the full y (d_y is this rank's slice of it)
+            sharding_mod.allgather_y(dist, d_y, d_y_full, bounds)
 
     # correctness gate before any timing
     step()
@@ -269,7 +272,7 @@ def main():
 
     # ------------------------------------------------------------ headline: CSR on the workload
     blk = build_block(sm, sharding, args.workload, args, rank, world)
-    res = measure_csr(torch, dist, sm, blk, args, world, local_rank, rank, args.steps, args.warmup,
+    res = measure_csr(torch, dist, sm, sharding, blk, args, world, local_rank, rank, args.steps, args.warmup,
                       collective=not args.no_allgather)
     gflops = 2.0 * res["nnz_total"] / res["wall_per_step"] * 1e-9
     extra = {"device": dev_name, "compute_units": cus, "nnz": int(res["nnz_total"]), "rows": blk["rows_total"],
@@ -354,7 +357,7 @@ def main():
     if args.workload == "memplus_tiled" and not args.no_random_model and world == 1:
         try:
             blk2 = build_block(sm, sharding, "memplus_shaped", args, rank, world)
-            r2 = measure_csr(torch, dist, sm, blk2, args, world, local_rank, rank, max(10, args.steps // 4), 3, False)
+            r2 = measure_csr(torch, dist, sm, sharding, blk2, args, world, local_rank, rank, max(10, args.steps // 4), 3, False)
             rl = roofline_of(r2)
             far = float((np.abs(np.repeat(np.arange(blk2["rows"]), np.diff(blk2["row_ptr"])) - blk2["col_ind"]) > 4096).mean())
             extra["survey_random_model"] = {

@@ -376,3 +376,49 @@ def test_cli_ref_quirks_reproduces_reference_tjds_report(torch, tmp_path):
     got = open(tmp_path / os.listdir(tmp_path)[0]).read()
     want = ob.read_report("smvp-toolbox_report_TJDS_%s.txt" % REPORTS[name][1])
     assert ob.report_y_lines(got) == ob.report_y_lines(want)
+
+
+# ------------------------------------------------------------- BASELINE config 4
+def test_uniform32_config4_shape(torch):
+    """10 M x 10 M, 32 uniform entries per row (BASELINE config 4) at 1/10 size: oracle on a slice + row sums."""
+    M = 1_000_000
+    row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_UNIFORM, 2024, M, M, param=32)
+    x = np.random.default_rng(4).random(M)
+    A = sm.CsrMatrix(M, M, row_ptr, col_ind, val)
+    dx = dev(torch, x)
+    scale = np.add.reduceat(np.abs(val * x[col_ind]), row_ptr[:-1])
+    host = np.add.reduceat(val * x[col_ind], row_ptr[:-1])
+    for kernel, param in ((sm.CSR_KERNEL_STREAM, 0), (sm.CSR_KERNEL_VECTOR, 32), (sm.CSR_KERNEL_VECTOR, 64)):
+        A.set_kernel(kernel, param)
+        dy = torch.full((M,), float("nan"), dtype=torch.float64, device="cuda")
+        A.spmv(dx, dy)
+        torch.cuda.synchronize()
+        y = dy.cpu().numpy()
+        assert np.all(np.abs(y - host) <= TOL * scale)
+        k = 50_000
+        ref = ob.csr_spmv(row_ptr[:k + 1].copy(), col_ind[:row_ptr[k]], val[:row_ptr[k]], x)
+        assert np.all(np.abs(y[:k] - ref) <= TOL * scale[:k])
+    A.close()
+
+
+def test_bench_script_runs_small(torch):
+    """bench.py end to end at toy size: one JSON line with the contract's keys, roofline and cpu_baseline."""
+    import json
+    import sys
+
+    from conftest import ROOT
+
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--copies", "8", "--rows-log2", "16",
+                        "--steps", "5", "--warmup", "2", "--cpu-iters", "2"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j
+    assert j["n_gpus"] == 1 and j["steps"] == 5 and j["dtype"] == "f64" and j["value"] > 0
+    assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
+    assert j["cpu_baseline"]["cores"] == 1 and j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["agrees_with_gpu"]
+    assert j["extra"]["full_size_parity"]["y_equals_tiled_reference_memplus_y"]
+    assert "error" not in j["extra"]["tjds"] and "error" not in j["extra"]["survey_random_model"]

@@ -41,8 +41,13 @@ def _worker(rank, world, port, case, out):
             r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
             row_ptr, col_ind, val = sharding.slice_csr(rp, ci, v, r0, r1)
             x = np.ones(N)
-        y_local = torch.from_numpy(ob.csr_spmv(row_ptr, col_ind, val, x))
         y_full = torch.full((M,), float("nan"), dtype=torch.float64)
+        if case == "synthetic_equal_rows":
+            # like bench.py: the local block is a view of the full vector and is gathered in place
+            y_local = y_full[r0:r1]
+            y_local.copy_(torch.from_numpy(ob.csr_spmv(row_ptr, col_ind, val, x)))
+        else:
+            y_local = torch.from_numpy(ob.csr_spmv(row_ptr, col_ind, val, x))
         sharding.allgather_y(dist, y_local, y_full, bounds)
         if rank == 0:
             np.save(out, y_full.numpy())
