@@ -264,10 +264,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    # one rank per GPU; SMVP_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the sharded path
+    backend = os.environ.get("SMVP_DIST_BACKEND", "nccl")
+    local_rank %= max(1, torch.cuda.device_count()) if backend != "nccl" else max(1, local_rank + 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev_name, cus, hbm = sm.device_info(local_rank)
 
     # ------------------------------------------------------------ headline: CSR on the workload
