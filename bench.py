@@ -214,7 +214,7 @@ def measure_csr(torch, dist, sm, sharding_mod, blk, args, world, local_rank, ran
     return res
 
 
-def recorded_traffic(workload, kernel):
+def recorded_traffic(workload, kernel, alg_bytes):
     """HBM bytes per launch from the committed PMC passes (profiles/*traffic.json), if one matches this run.
 
     PMC counters cannot be read from inside the benchmark; tools/profile_bench.sh collects them in separate
@@ -228,7 +228,9 @@ def recorded_traffic(workload, kernel):
             t = json.load(open(f))
         except Exception:
             continue
-        if t.get("workload") == workload and t.get("kernel") == kernel and t.get("traffic_bytes_per_launch"):
+        same_launch = abs(t.get("alg_bytes_per_launch", 0) - alg_bytes) <= 0.01 * alg_bytes
+        if (t.get("workload") == workload and t.get("kernel") == kernel and same_launch
+                and t.get("traffic_bytes_per_launch")):
             best = (t["traffic_bytes_per_launch"], os.path.basename(f))
     return best
 
@@ -239,7 +241,7 @@ def roofline_of(res, workload=None):
          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
          "alg_bytes_per_launch": res["alg_bytes_local"], "ms_per_launch": round(res["kernel_ms"], 5),
          "note": "per launch = CSR kernel + its 5 us carry fix-up, HIP events on the launch stream"}
-    rec = recorded_traffic(workload, res["kernel"]) if workload else None
+    rec = recorded_traffic(workload, res["kernel"], res["alg_bytes_local"]) if workload else None
     if rec:
         r["traffic"] = rec[0]
         r["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" % rec[1]
@@ -384,7 +386,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(res["wall_per_step"] * 1e3, 5), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": blk["name"] + ", CSR, x=%s" % args.x +
-                       (", %d row blocks + RCCL all-gather of y" % world if world > 1 and not args.no_allgather else ""),
+                       (", %d row blocks + %s all-gather of y" % (world, "RCCL" if backend == "nccl" else backend)
+                        if world > 1 and not args.no_allgather else ""),
                        "format": "csr", "kernel": res["kernel"], "nnz": int(res["nnz_total"]),
                        "rows": blk["rows_total"], "sharding": "row-block x%d" % world},
             "roofline": headline_roofline, "cpu_baseline": cpu, "extra": extra,

@@ -60,9 +60,11 @@ def fixture_path(name):
     os.makedirs(cache, exist_ok=True)
     out = os.path.join(cache, name)
     if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(gz):
-        with gzip.open(gz, "rb") as src, open(out + ".tmp", "wb") as dst:
+        # several ranks may get here together: each inflates into its own temp file, the rename is atomic
+        fd, tmp = tempfile.mkstemp(prefix=name + ".", dir=cache)
+        with gzip.open(gz, "rb") as src, os.fdopen(fd, "wb") as dst:
             shutil.copyfileobj(src, dst)
-        os.replace(out + ".tmp", out)
+        os.replace(tmp, out)
     return out
 
 
