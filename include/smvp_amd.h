@@ -126,8 +126,11 @@ int smvp_device_info(int device, char *name, size_t name_cap, int *compute_units
  * statistics at create time. */
 enum {
     SMVP_CSR_KERNEL_AUTO = 0,
-    SMVP_CSR_KERNEL_VECTOR = 1, /* one (sub-)wavefront per row, __shfl_down sums */
-    SMVP_CSR_KERNEL_STREAM = 2  /* fixed-nnz tiles, LDS-staged segmented reduction */
+    SMVP_CSR_KERNEL_VECTOR = 1,      /* one (sub-)wavefront per row, __shfl_down sums */
+    SMVP_CSR_KERNEL_STREAM = 2,      /* fixed-nnz tiles, LDS-staged segmented reduction; a row is finished by
+                                        the tile it starts in (one launch) */
+    SMVP_CSR_KERNEL_STREAM_CARRY = 3 /* same tiles; a row that crosses tiles is combined from per-tile carries
+                                        by a second small launch (for matrices with extremely long rows) */
 };
 enum {
     SMVP_MEM_HOST = 0,  /* arrays are host memory: copied to the device */

@@ -19,7 +19,7 @@
  *     recognised and refused: out of scope for the GPU engine.
  *   - libpopt is not used (absent from the image): getopt_long("+...") gives the
  *     same POSIX ordering rule.
- * Additive flags: --device N, --ref-quirks, --csr-kernel auto|vector|stream,
+ * Additive flags: --device N, --ref-quirks, --csr-kernel auto|vector|stream|stream-carry,
  * --quiet-arrays is implied (the reference's SMVP_CSR_DEBUG array dumps,
  * main-cli.c:374-394, are not printed).
  */
@@ -49,7 +49,7 @@ static void usage(FILE *to, const char *prog)
     fprintf(to,
             "Usage: %s [-acgt?] [-a|--all-algs] [-c|--csr] [-g|--cisr-gen] [-t|--tjds]\n"
             "        [-n|--number=1000] [-s|--slots=16] [-d|--dir=./] [--device=0]\n"
-            "        [--ref-quirks] [--csr-kernel=auto|vector|stream] [-?|--help] [--usage]\n"
+            "        [--ref-quirks] [--csr-kernel=auto|vector|stream|stream-carry] [-?|--help] [--usage]\n"
             "        [OPTIONS] <file>\n",
             prog);
 }
@@ -66,7 +66,7 @@ static void help(const char *prog)
     puts("  -d, --dir=./             Output folder for reports.");
     puts("      --device=0           HIP device ordinal.");
     puts("      --ref-quirks         Reproduce the reference v0.6.4 TJDS output, defects included.");
-    puts("      --csr-kernel=auto    CSR kernel family: auto, vector, stream.");
+    puts("      --csr-kernel=auto    CSR kernel family: auto, vector, stream, stream-carry.");
     puts("\nHelp options:");
     puts("  -?, --help               Show this help message");
     puts("      --usage              Display brief usage message");
@@ -202,8 +202,10 @@ int main(int argc, char *argv[])
                 csr_kernel = SMVP_CSR_KERNEL_VECTOR;
             else if (strcmp(optarg, "stream") == 0)
                 csr_kernel = SMVP_CSR_KERNEL_STREAM;
+            else if (strcmp(optarg, "stream-carry") == 0)
+                csr_kernel = SMVP_CSR_KERNEL_STREAM_CARRY;
             else
-                die("Unknown CSR kernel family (use auto, vector or stream).");
+                die("Unknown CSR kernel family (use auto, vector, stream or stream-carry).");
             break;
         case OPT_USAGE:
             usage(stdout, prog);

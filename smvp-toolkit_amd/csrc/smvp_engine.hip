@@ -77,9 +77,11 @@ struct smvp_csr {
     int lanes_per_row = 64;             // VECTOR
     int vpt = 4;                        // STREAM: entries per thread (tile = 256 * vpt)
     int ntiles = 0;
+    int max_row_len = 0;
     int *d_tile_row = nullptr;
-    int *d_carry_row = nullptr;
-    double *d_carry = nullptr;
+    int *d_tile_next = nullptr;   // STREAM: row_ptr[first row of the next tile]
+    int *d_carry_row = nullptr;   // STREAM_CARRY
+    double *d_carry = nullptr;    // STREAM_CARRY
 };
 
 namespace {
@@ -92,7 +94,9 @@ void free_stream_plan(smvp_csr *h)
         (void)hipFree(h->d_carry_row);
     if (h->d_carry)
         (void)hipFree(h->d_carry);
-    h->d_tile_row = h->d_carry_row = nullptr;
+    if (h->d_tile_next)
+        (void)hipFree(h->d_tile_next);
+    h->d_tile_row = h->d_carry_row = h->d_tile_next = nullptr;
     h->d_carry = nullptr;
     h->ntiles = 0;
 }
@@ -105,7 +109,7 @@ int build_stream_plan(smvp_csr *h)
     const int tile = smvp::kStreamBlock * h->vpt;
     const long long nnz = h->nnz;
     const int ntiles = (int)std::max<long long>(1, (nnz + tile - 1) / tile);
-    std::vector<int> tile_row((size_t)ntiles + 1), carry_row((size_t)ntiles);
+    std::vector<int> tile_row((size_t)ntiles + 1), carry_row((size_t)ntiles), tile_next((size_t)ntiles);
     const int *rp = h->h_row_ptr.data();
     int r = 0;
     for (int b = 0; b < ntiles; ++b) {
@@ -118,12 +122,19 @@ int build_stream_plan(smvp_csr *h)
         carry_row[(size_t)b] = (std::min(first, e) > s) ? r - 1 : -1;
     }
     tile_row[(size_t)ntiles] = h->rows;
+    for (int b = 0; b < ntiles; ++b)
+        tile_next[(size_t)b] = rp[tile_row[(size_t)b + 1]];
     if (int rc = upload(&h->d_tile_row, tile_row))
         return rc;
-    if (int rc = upload(&h->d_carry_row, carry_row))
-        return rc;
-    HIP_TRY(hipMalloc((void **)&h->d_carry, std::max(ntiles, 1) * sizeof(double)));
-    HIP_TRY(hipMemset(h->d_carry, 0, std::max(ntiles, 1) * sizeof(double)));
+    if (h->kernel == SMVP_CSR_KERNEL_STREAM) {
+        if (int rc = upload(&h->d_tile_next, tile_next))
+            return rc;
+    } else {
+        if (int rc = upload(&h->d_carry_row, carry_row))
+            return rc;
+        HIP_TRY(hipMalloc((void **)&h->d_carry, std::max(ntiles, 1) * sizeof(double)));
+        HIP_TRY(hipMemset(h->d_carry, 0, std::max(ntiles, 1) * sizeof(double)));
+    }
     h->ntiles = ntiles;
     return SMVP_OK;
 }
@@ -137,13 +148,21 @@ int pow2_at_least(double v)
 }
 
 // AUTO: fixed-nnz tiles are insensitive to row-length skew and keep short rows
-// at full lane use, so they are the default; very long uniform rows go to the
-// wavefront-per-row kernel.
+// at full lane use, so they are the default -- the owner-completes form unless
+// some row is so long that one workgroup finishing it alone would be the
+// critical path (then the carry form, which spreads a row over its tiles);
+// uniformly long rows go to the wavefront-per-row kernel.
+constexpr int kOwnerMaxRow = 16 * 1024;
+
 void choose_csr_kernel(smvp_csr *h, int kernel, int param)
 {
     const double mean = h->rows > 0 ? (double)h->nnz / h->rows : 0.0;
-    if (kernel == SMVP_CSR_KERNEL_AUTO)
-        kernel = mean >= 96.0 ? SMVP_CSR_KERNEL_VECTOR : SMVP_CSR_KERNEL_STREAM;
+    if (kernel == SMVP_CSR_KERNEL_AUTO) {
+        if (mean >= 96.0)
+            kernel = SMVP_CSR_KERNEL_VECTOR;
+        else
+            kernel = h->max_row_len > kOwnerMaxRow ? SMVP_CSR_KERNEL_STREAM_CARRY : SMVP_CSR_KERNEL_STREAM;
+    }
     h->kernel = kernel;
     if (kernel == SMVP_CSR_KERNEL_VECTOR) {
         h->lanes_per_row = param > 0 ? param : pow2_at_least(mean);
@@ -183,8 +202,10 @@ extern "C" int smvp_csr_create(smvp_csr_t **out, int device, int rows, int cols,
     if (rc == SMVP_OK) {
         const std::vector<int> &rp = h->h_row_ptr;
         bool ok = rp[0] == 0 && rp[(size_t)rows] == nnz;
-        for (int r = 0; r < rows && ok; ++r)
+        for (int r = 0; r < rows && ok; ++r) {
             ok = rp[(size_t)r] <= rp[(size_t)r + 1];
+            h->max_row_len = std::max(h->max_row_len, rp[(size_t)r + 1] - rp[(size_t)r]);
+        }
         if (!ok)
             rc = smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: row_ptr is not a non-decreasing 0..nnz sequence");
     }
@@ -206,7 +227,7 @@ extern "C" int smvp_csr_create(smvp_csr_t **out, int device, int rows, int cols,
         rc = to_device(&h->d_val, val, (size_t)nnz, mem_kind, &h->own_val);
     if (rc == SMVP_OK) {
         choose_csr_kernel(h, SMVP_CSR_KERNEL_AUTO, 0);
-        if (h->kernel == SMVP_CSR_KERNEL_STREAM)
+        if (h->kernel != SMVP_CSR_KERNEL_VECTOR)
             rc = build_stream_plan(h);
     }
     if (rc != SMVP_OK) {
@@ -221,16 +242,17 @@ extern "C" int smvp_csr_set_kernel(smvp_csr_t *h, int kernel, int param)
 {
     if (!h)
         return smvp::fail(SMVP_ERR_INVALID, "null handle");
-    if (kernel < SMVP_CSR_KERNEL_AUTO || kernel > SMVP_CSR_KERNEL_STREAM)
+    if (kernel < SMVP_CSR_KERNEL_AUTO || kernel > SMVP_CSR_KERNEL_STREAM_CARRY)
         return smvp::fail(SMVP_ERR_INVALID, "unknown CSR kernel %d", kernel);
     if (kernel == SMVP_CSR_KERNEL_VECTOR && param != 0 &&
         (param < 2 || param > 64 || (param & (param - 1)) != 0))
         return smvp::fail(SMVP_ERR_INVALID, "lanes per row must be a power of two in [2, 64]");
-    if (kernel == SMVP_CSR_KERNEL_STREAM && param != 0 && param != 1024 && param != 2048)
+    if ((kernel == SMVP_CSR_KERNEL_STREAM || kernel == SMVP_CSR_KERNEL_STREAM_CARRY) && param != 0 && param != 1024 &&
+        param != 2048)
         return smvp::fail(SMVP_ERR_INVALID, "entries per tile must be 1024 or 2048");
     HIP_TRY(hipSetDevice(h->device));
     choose_csr_kernel(h, kernel, param);
-    if (h->kernel == SMVP_CSR_KERNEL_STREAM)
+    if (h->kernel != SMVP_CSR_KERNEL_VECTOR)
         return build_stream_plan(h);
     free_stream_plan(h);
     return SMVP_OK;
@@ -255,6 +277,9 @@ extern "C" int smvp_csr_spmv(smvp_csr_t *h, const double *d_x, double *d_y, void
     hipError_t e;
     if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
         e = smvp::launch_csr_vector(h->lanes_per_row, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y, h->rows, st);
+    else if (h->kernel == SMVP_CSR_KERNEL_STREAM)
+        e = smvp::launch_csr_stream_owner(h->vpt, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y, h->d_tile_row,
+                                          h->d_tile_next, h->rows, h->nnz, h->ntiles, st);
     else
         e = smvp::launch_csr_stream(h->vpt, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y, h->d_tile_row,
                                     h->d_carry_row, h->d_carry, h->rows, h->nnz, h->ntiles, st);
@@ -270,6 +295,8 @@ extern "C" int smvp_csr_describe(const smvp_csr_t *h, char *kernel_name, size_t 
     if (kernel_name && cap) {
         if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
             snprintf(kernel_name, cap, "csr_vector_rows<%d>", h->lanes_per_row);
+        else if (h->kernel == SMVP_CSR_KERNEL_STREAM)
+            snprintf(kernel_name, cap, "csr_stream_owner<%d>", h->vpt);
         else
             snprintf(kernel_name, cap, "csr_stream_tiles<%d>", h->vpt);
     }

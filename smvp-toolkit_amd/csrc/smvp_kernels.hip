@@ -174,6 +174,146 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_tiles(
     }
 }
 
+// ---------------------------------------------------------------------------
+// K2': the same tiles, but the tile in which a row STARTS finishes that row
+// itself: it also loads the few entries past its end that belong to its last
+// row (tile_next[b] = row_ptr[first row of the next tile] says how many) into an
+// LDS overflow area.  No carries, no second launch, and every row of up to
+// kLongRow entries is summed left to right by one lane -- bit-identical to the
+// serial loop -- wherever it lies.  A tile in which no row starts exits at once.
+// A last row that runs more than kStreamOver entries past the tile is finished
+// by the whole workgroup straight from global memory; matrices with rows far
+// longer than that are planned onto the carry kernel above instead, which
+// spreads such a row over many workgroups.
+// ---------------------------------------------------------------------------
+template <int VPT>
+__global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
+    const int *__restrict__ row_ptr, const int *__restrict__ col_ind, const double *__restrict__ val,
+    const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ tile_row,
+    const int *__restrict__ tile_next, int rows, int nnz, int ntiles, int tiles_per_xcd)
+{
+    constexpr int TILE = kStreamBlock * VPT;
+    constexpr int QCAP = (TILE + kStreamOver) / kLongRow + 1;
+    __shared__ double prod[TILE + kStreamOver];
+    __shared__ int long_rows[QCAP];
+    __shared__ int long_count;
+    __shared__ double wave_sum[kStreamBlock / 64];
+
+    const int b = xcd_contiguous_tile(blockIdx.x, tiles_per_xcd);
+    if (b >= ntiles)
+        return;
+    const int rlo = tile_row[b];
+    const int rhi = tile_row[b + 1];
+    if (rlo == rhi)
+        return;  // all of this tile continues a row owned by an earlier tile
+    const int t = threadIdx.x;
+    const long long s = (long long)b * TILE;
+    const int lo = (int)s;  // nnz < 2^31
+    const int e = (int)(s + TILE < (long long)nnz ? s + TILE : (long long)nnz);
+    const int zend = tile_next[b];  // row_ptr[rhi]: end of the last owned row, >= e
+    const int ext = zend - e;
+    const bool giant = ext > kStreamOver;
+    if (t == 0)
+        long_count = 0;
+
+    // ---- phase 1: stream + gather + multiply (straight-line: all gathers of a lane in flight together)
+    const long long j0 = s + (long long)t * VPT;
+    double p[VPT];
+    if (j0 + VPT <= (long long)nnz) {
+        int c[VPT];
+        double v[VPT];
+#pragma unroll
+        for (int k = 0; k < VPT; k += 4)
+            *reinterpret_cast<int4 *>(&c[k]) = *reinterpret_cast<const int4 *>(col_ind + j0 + k);
+#pragma unroll
+        for (int k = 0; k < VPT; k += 2)
+            *reinterpret_cast<double2 *>(&v[k]) = *reinterpret_cast<const double2 *>(val + j0 + k);
+#pragma unroll
+        for (int k = 0; k < VPT; ++k)
+            p[k] = v[k] * x[c[k]];
+        if (!giant)
+            for (int i = t; i < ext; i += kStreamBlock)
+                prod[e - lo + i] = val[e + i] * x[col_ind[e + i]];
+    } else {
+#pragma unroll
+        for (int k = 0; k < VPT; ++k)
+            p[k] = (j0 + k < (long long)nnz) ? val[j0 + k] * x[col_ind[j0 + k]] : 0.0;
+        if (!giant)
+            for (int i = t; i < ext; i += kStreamBlock)
+                prod[e - lo + i] = val[e + i] * x[col_ind[e + i]];
+    }
+#pragma unroll
+    for (int k = 0; k < VPT; k += 2)
+        *reinterpret_cast<double2 *>(&prod[t * VPT + k]) = make_double2(p[k], p[k + 1]);
+    __syncthreads();
+
+    // ---- phase 2b: one lane per owned row, long rows deferred
+    const int last = rhi - 1;
+    for (int r = rlo + t; r < rhi; r += kStreamBlock) {
+        if (giant && r == last)
+            continue;
+        const int a = row_ptr[r];
+        const int z = row_ptr[r + 1];
+        if (z - a <= kLongRow) {
+            double acc = 0.0;
+            for (int i = a - lo; i < z - lo; ++i)
+                acc += prod[i];
+            y[r] = acc;
+        } else {
+            long_rows[atomicAdd(&long_count, 1)] = r;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2c: one wavefront per long row
+    const int nlong = long_count;
+    const int lane = t & 63;
+    for (int q = t >> 6; q < nlong; q += kStreamBlock / 64) {
+        const int r = long_rows[q];
+        const int a = row_ptr[r];
+        const int z = row_ptr[r + 1];
+        double acc = 0.0;
+        for (int i = a - lo + lane; i < z - lo; i += 64)
+            acc += prod[i];
+        acc = shfl_down_sum<64>(acc);
+        if (lane == 0)
+            y[r] = acc;
+    }
+
+    // ---- phase 2d: a last row that runs far past the tile: LDS part + the rest from global memory
+    if (giant) {
+        const int a = row_ptr[last];
+        double acc = 0.0;
+        for (int i = a - lo + t; i < e - lo; i += kStreamBlock)
+            acc += prod[i];
+        for (int j = e + t; j < zend; j += 4 * kStreamBlock) {
+            int c[4];
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jj = j + u * kStreamBlock;
+                const bool in = jj < zend;
+                c[u] = in ? col_ind[jj] : 0;
+                v[u] = in ? val[jj] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                acc += (j + u * kStreamBlock < zend) ? v[u] * x[c[u]] : 0.0;
+        }
+        acc = shfl_down_sum<64>(acc);
+        if (lane == 0)
+            wave_sum[t >> 6] = acc;
+        __syncthreads();
+        if (t == 0) {
+            double total = 0.0;
+#pragma unroll
+            for (int w = 0; w < kStreamBlock / 64; ++w)
+                total += wave_sum[w];
+            y[last] = total;
+        }
+    }
+}
+
 // One thread per tile; the head of each run of tiles that feed the same row adds
 // their carries to that row in tile order.
 __global__ __launch_bounds__(256) void csr_stream_carry_fixup(
@@ -208,16 +348,31 @@ __global__ __launch_bounds__(kTjdsBlock) void tjds_colmajor_scatter(
     const int4 w = work[blockIdx.x];  // x = first column, y = first diagonal, z = one past the last
     const int k = w.x + threadIdx.x;
     const double xk = (!OPERAND_BY_ROW && k < cols) ? x_perm[k] : 0.0;
-    for (int d = w.y; d < w.z; ++d) {
-        const int base = start_pos[d];
-        if (k >= start_pos[d + 1] - base)
-            break;  // diagonal lengths never grow with d
-        const int j = base + k;
-        const int r = row_ind[j];
-        // main-cli.c:1018 indexes the permuted operand by the row; the corrected
-        // product uses the column's own entry
-        const double xv = OPERAND_BY_ROW ? x_perm[r] : xk;
-        unsafeAtomicAdd(&y[r], val[j] * xv);
+    // all loads of the chunk first (they are independent), then the atomics: a loop that
+    // loaded and added one diagonal at a time paid one memory round trip per diagonal
+    int r[kTjdsDiagChunk];
+    double v[kTjdsDiagChunk];
+#pragma unroll
+    for (int i = 0; i < kTjdsDiagChunk; ++i) {
+        const int d = w.y + i;
+        r[i] = -1;
+        v[i] = 0.0;
+        if (d < w.z) {
+            const int base = start_pos[d];
+            if (k < start_pos[d + 1] - base) {  // diagonal lengths never grow with d
+                r[i] = row_ind[base + k];
+                v[i] = val[base + k];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kTjdsDiagChunk; ++i) {
+        if (r[i] >= 0) {
+            // main-cli.c:1018 indexes the permuted operand by the row; the corrected
+            // product uses the column's own entry
+            const double xv = OPERAND_BY_ROW ? x_perm[r[i]] : xk;
+            unsafeAtomicAdd(&y[r[i]], v[i] * xv);
+        }
     }
 }
 
@@ -294,6 +449,29 @@ hipError_t launch_csr_stream(int vpt, const int *row_ptr, const int *col_ind, co
         e = hipGetLastError();
     }
     return e;
+}
+
+hipError_t launch_csr_stream_owner(int vpt, const int *row_ptr, const int *col_ind, const double *val,
+                                   const double *x, double *y, const int *tile_row, const int *tile_next,
+                                   int rows, int nnz, int ntiles, hipStream_t stream)
+{
+    if (rows <= 0)
+        return hipSuccess;
+    const int tiles_per_xcd = (ntiles + 7) / 8;
+    const dim3 grid((unsigned)tiles_per_xcd * 8u);
+    switch (vpt) {
+    case 4:
+        hipLaunchKernelGGL(csr_stream_owner<4>, grid, dim3(kStreamBlock), 0, stream, row_ptr, col_ind, val, x, y,
+                           tile_row, tile_next, rows, nnz, ntiles, tiles_per_xcd);
+        break;
+    case 8:
+        hipLaunchKernelGGL(csr_stream_owner<8>, grid, dim3(kStreamBlock), 0, stream, row_ptr, col_ind, val, x, y,
+                           tile_row, tile_next, rows, nnz, ntiles, tiles_per_xcd);
+        break;
+    default:
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_tjds_scatter(bool operand_by_row, const int *start_pos, const int *row_ind, const double *val,

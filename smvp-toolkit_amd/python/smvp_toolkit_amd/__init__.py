@@ -19,7 +19,7 @@ CLI_PATH = os.path.join(PKG_ROOT, "bin", "smvp-toolkit-cli")
 OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_IO, ERR_UNSUPPORTED = 1, 2, 3, 4, 5, 6
 MM_COULD_NOT_READ_FILE, MM_PREMATURE_EOF, MM_NOT_MTX, MM_NO_HEADER, MM_UNSUPPORTED_TYPE = 11, 12, 13, 14, 15
-CSR_KERNEL_AUTO, CSR_KERNEL_VECTOR, CSR_KERNEL_STREAM = 0, 1, 2
+CSR_KERNEL_AUTO, CSR_KERNEL_VECTOR, CSR_KERNEL_STREAM, CSR_KERNEL_STREAM_CARRY = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 SYNTH_MEMPLUS_SHAPED, SYNTH_UNIFORM = 1, 2
 

@@ -26,7 +26,8 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-9
 EXACT = {"ibm32.mtx", "curtis54.mtx", "pwt.mtx", "pdp08-pg4.mtx"}
 
-CSR_VARIANTS = [(sm.CSR_KERNEL_STREAM, 1024), (sm.CSR_KERNEL_STREAM, 2048)] + \
+CSR_VARIANTS = [(sm.CSR_KERNEL_STREAM, 1024), (sm.CSR_KERNEL_STREAM, 2048),
+                (sm.CSR_KERNEL_STREAM_CARRY, 1024), (sm.CSR_KERNEL_STREAM_CARRY, 2048)] + \
                [(sm.CSR_KERNEL_VECTOR, t) for t in (2, 4, 8, 16, 32, 64)]
 
 
@@ -83,7 +84,7 @@ def test_csr_sample_matrices_ones(torch, name, kernel, param):
     ref = ob.csr_spmv(row_ptr, col_ind, val, x)
     y = gpu_csr(torch, m, n, row_ptr, col_ind, val, x, kernel, param)
     assert_close(y, ref, row_scale(row_ptr, col_ind, val, x), exact=name in EXACT)
-    if name in EXACT or kernel == sm.CSR_KERNEL_STREAM:
+    if name in EXACT or kernel in (sm.CSR_KERNEL_STREAM, sm.CSR_KERNEL_STREAM_CARRY):
         # the %g text of the report must equal the reference's committed report
         want = ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_%s.txt" % REPORTS[name][0]))
         got = ob.fmt_g(y)
@@ -103,18 +104,39 @@ def test_csr_sample_matrices_general_x(torch, name, kernel, param):
 
 
 def test_stream_kernel_is_bitwise_serial_on_short_rows(torch):
-    """Rows that fit one tile and are summed by one lane reproduce the serial loop bit for bit."""
+    """Every row of up to 32 entries is summed left to right by one lane: bit for bit the serial loop."""
     m, n, coo = load("memplus.mtx")
     row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
     x = np.random.default_rng(1).random(n)
     ref = ob.csr_spmv(row_ptr, col_ind, val, x)
-    y = gpu_csr(torch, m, n, row_ptr, col_ind, val, x, sm.CSR_KERNEL_STREAM, 1024)
     lens = np.diff(row_ptr)
-    tile_of_first = row_ptr[:-1] // 1024
-    tile_of_last = (np.maximum(row_ptr[1:], 1) - 1) // 1024
-    one_lane = (lens <= 32) & (tile_of_first == tile_of_last)
-    assert one_lane.mean() > 0.9
-    assert np.array_equal(y[one_lane], ref[one_lane])
+    for tile in (1024, 2048):
+        # owner form: wherever the row lies, also across a tile edge
+        y = gpu_csr(torch, m, n, row_ptr, col_ind, val, x, sm.CSR_KERNEL_STREAM, tile)
+        short = lens <= 32
+        assert short.mean() > 0.98
+        assert np.array_equal(y[short], ref[short])
+        # carry form: rows that fit one tile
+        y = gpu_csr(torch, m, n, row_ptr, col_ind, val, x, sm.CSR_KERNEL_STREAM_CARRY, tile)
+        one_tile = short & (row_ptr[:-1] // tile == (np.maximum(row_ptr[1:], 1) - 1) // tile)
+        assert one_tile.mean() > 0.9
+        assert np.array_equal(y[one_tile], ref[one_tile])
+
+
+def test_auto_plan_choice(torch):
+    """AUTO: owner-completes tiles by default, the carry form when some row is extremely long, vector for long means."""
+    rng = np.random.default_rng(11)
+    for lens, want in (([5] * 3000, sm.CSR_KERNEL_STREAM), ([3] * 500 + [40000] + [2] * 500, sm.CSR_KERNEL_STREAM_CARRY),
+                       ([128] * 300, sm.CSR_KERNEL_VECTOR)):
+        row_ptr, col_ind, val = csr_from_lengths(rng, lens, 50000)
+        A = sm.CsrMatrix(len(lens), 50000, row_ptr, col_ind, val)
+        assert A.get_kernel()[0] == want
+        x = rng.random(50000)
+        dy = torch.empty(len(lens), dtype=torch.float64, device="cuda")
+        A.spmv(dev(torch, x), dy)
+        torch.cuda.synchronize()
+        assert_close(dy.cpu().numpy(), ob.csr_spmv(row_ptr, col_ind, val, x), row_scale(row_ptr, col_ind, val, x))
+        A.close()
 
 
 @pytest.mark.parametrize("name", SAMPLES)
@@ -191,6 +213,8 @@ EDGE_CASES = {
     "all_rows_empty_but_one": lambda rng: ([0] * 500 + [40] + [0] * 500, 64),
     "row_spanning_many_tiles": lambda rng: ([3, 5000, 2, 0, 7000, 1], 8192),
     "row_ending_exactly_on_tile_edges": lambda rng: ([1024, 1024, 2048, 1, 1023], 4096),
+    "rows_just_past_a_tile_edge": lambda rng: ([1020, 5, 1, 1000, 30, 260, 763, 1, 300, 700, 280], 4096),
+    "one_huge_row_between_short_ones": lambda rng: ([2] * 100 + [40000] + [3] * 100, 65536),
     "many_short_rows": lambda rng: (rng.integers(0, 4, 20000).tolist(), 300),
     "mixed_skew": lambda rng: (np.where(rng.random(3000) < 0.01, rng.integers(200, 3000, 3000),
                                         rng.integers(0, 12, 3000)).tolist(), 5000),

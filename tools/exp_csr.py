@@ -47,7 +47,7 @@ def main():
     ref = None
     for var in a.variants.split(","):
         fam, par = var.split(":")
-        A.set_kernel({"stream": 2, "vector": 1}[fam], int(par))
+        A.set_kernel({"stream": 2, "vector": 1, "carry": 3}[fam], int(par))
         name, nbytes = A.describe()
         for _ in range(3):
             A.spmv(x, y)

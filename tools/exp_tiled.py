@@ -29,7 +29,7 @@ def main():
     x = torch.ones(cols, dtype=torch.float64, device="cuda"); y = torch.empty(rows, dtype=torch.float64, device="cuda")
     ybase = ob.csr_spmv(rp, ci, v, np.ones(n))
     for var in a.variants.split(","):
-        fam, par = var.split(":"); A.set_kernel({"stream": 2, "vector": 1}[fam], int(par)); name, nbytes = A.describe()
+        fam, par = var.split(":"); A.set_kernel({"stream": 2, "vector": 1, "carry": 3}[fam], int(par)); name, nbytes = A.describe()
         for _ in range(100): A.spmv(x, y)
         torch.cuda.synchronize()
         err = float((y.view(copies, m) - torch.from_numpy(ybase).cuda()[None, :]).abs().max())

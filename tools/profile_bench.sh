@@ -16,7 +16,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 cp "$OUT/trace/t_kernel_stats.csv" "$OUT/kernel_stats.csv" 2>/dev/null
 cd $R
 bash tools/pmc_passes.sh gpurun_out/profile_$TAG/pmc -- python3 $R/bench.py --steps 10 --warmup 2 $ARGS > /dev/null
-python3 tools/pmc_summary.py "$OUT/pmc" csr_stream_tiles > "$OUT/pmc_summary.txt"
+python3 tools/pmc_summary.py "$OUT/pmc" csr_stream_ > "$OUT/pmc_summary.txt"
 python3 - "$OUT" <<'PY'
 import json, re, sys
 out = sys.argv[1]
