@@ -13,6 +13,8 @@
 // by one lane is bit-identical to the serial CPU result.
 #include "smvp_kernels.h"
 
+#include <cstdlib>
+
 namespace smvp {
 
 // ---------------------------------------------------------------------------
@@ -27,13 +29,17 @@ __device__ __forceinline__ double shfl_down_sum(double v)
     return v;
 }
 
-// Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Give
-// each XCD one contiguous run of tiles so that the rows it works on -- and the
-// near-diagonal part of x they gather -- stay in that XCD's 4 MiB L2.  Speed
-// only: any placement gives the same result.
-__device__ __forceinline__ int xcd_contiguous_tile(int block, int tiles_per_xcd)
+// Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Tiles are
+// handed out in groups: XCD i takes `group` consecutive tiles out of every run of
+// 8*group, so an XCD's L2 sees neighbouring rows (and their near-diagonal x) while
+// all eight XCDs stay within 8*group tiles of each other in memory.  group = 1 is
+// the plain order.  Measured on MI355X (memplus x944 / pwt x459, % of HBM peak):
+// whole-matrix-per-XCD runs 60.1 / 64.4, plain order 63.8 / 71.2.
+// Speed only: any placement gives the same result.
+__device__ __forceinline__ int tile_of_block(int block, int group)
 {
-    return (block & 7) * tiles_per_xcd + (block >> 3);
+    const int xcd = block & 7, seq = block >> 3;
+    return (seq / group) * (8 * group) + xcd * group + seq % group;
 }
 
 // ---------------------------------------------------------------------------
@@ -82,7 +88,7 @@ template <int VPT>
 __global__ __launch_bounds__(kStreamBlock) void csr_stream_tiles(
     const int *__restrict__ row_ptr, const int *__restrict__ col_ind, const double *__restrict__ val,
     const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ tile_row,
-    double *__restrict__ carry, int rows, int nnz, int ntiles, int tiles_per_xcd)
+    double *__restrict__ carry, int rows, int nnz, int ntiles, int tile_group)
 {
     constexpr int TILE = kStreamBlock * VPT;
     constexpr int QCAP = TILE / kLongRow + 1;
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_tiles(
     __shared__ int long_rows[QCAP];
     __shared__ int long_count;
 
-    const int b = xcd_contiguous_tile(blockIdx.x, tiles_per_xcd);
+    const int b = tile_of_block(blockIdx.x, tile_group);
     if (b >= ntiles)
         return;
     const int t = threadIdx.x;
@@ -190,7 +196,7 @@ template <int VPT>
 __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     const int *__restrict__ row_ptr, const int *__restrict__ col_ind, const double *__restrict__ val,
     const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ tile_row,
-    const int *__restrict__ tile_next, int rows, int nnz, int ntiles, int tiles_per_xcd)
+    const int *__restrict__ tile_next, int rows, int nnz, int ntiles, int tile_group)
 {
     constexpr int TILE = kStreamBlock * VPT;
     constexpr int QCAP = (TILE + kStreamOver) / kLongRow + 1;
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     __shared__ int long_count;
     __shared__ double wave_sum[kStreamBlock / 64];
 
-    const int b = xcd_contiguous_tile(blockIdx.x, tiles_per_xcd);
+    const int b = tile_of_block(blockIdx.x, tile_group);
     if (b >= ntiles)
         return;
     const int rlo = tile_row[b];
@@ -216,9 +222,13 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     if (t == 0)
         long_count = 0;
 
-    // ---- phase 1: stream + gather + multiply (straight-line: all gathers of a lane in flight together)
+    // ---- phase 1: stream + gather + multiply.  Straight-line code: the tile's own loads, the first
+    // kStreamBlock entries of the overflow, then ALL gathers, so that nothing waits on more than one
+    // dependent round trip (col_ind -> x).
     const long long j0 = s + (long long)t * VPT;
+    const bool over0 = !giant && t < ext;  // this lane fetches overflow entry e + t
     double p[VPT];
+    double po = 0.0;
     if (j0 + VPT <= (long long)nnz) {
         int c[VPT];
         double v[VPT];
@@ -228,23 +238,36 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
 #pragma unroll
         for (int k = 0; k < VPT; k += 2)
             *reinterpret_cast<double2 *>(&v[k]) = *reinterpret_cast<const double2 *>(val + j0 + k);
+        int co = 0;
+        double vo = 0.0;
+        if (over0) {
+            co = col_ind[e + t];
+            vo = val[e + t];
+        }
+        double xk[VPT];
 #pragma unroll
         for (int k = 0; k < VPT; ++k)
-            p[k] = v[k] * x[c[k]];
-        if (!giant)
-            for (int i = t; i < ext; i += kStreamBlock)
-                prod[e - lo + i] = val[e + i] * x[col_ind[e + i]];
+            xk[k] = x[c[k]];
+        const double xo = over0 ? x[co] : 0.0;
+#pragma unroll
+        for (int k = 0; k < VPT; ++k)
+            p[k] = v[k] * xk[k];
+        po = vo * xo;
     } else {
 #pragma unroll
         for (int k = 0; k < VPT; ++k)
             p[k] = (j0 + k < (long long)nnz) ? val[j0 + k] * x[col_ind[j0 + k]] : 0.0;
-        if (!giant)
-            for (int i = t; i < ext; i += kStreamBlock)
-                prod[e - lo + i] = val[e + i] * x[col_ind[e + i]];
+        if (over0)
+            po = val[e + t] * x[col_ind[e + t]];
     }
 #pragma unroll
     for (int k = 0; k < VPT; k += 2)
         *reinterpret_cast<double2 *>(&prod[t * VPT + k]) = make_double2(p[k], p[k + 1]);
+    if (over0)
+        prod[e - lo + t] = po;
+    if (!giant)  // rare: the last row runs more than one block width past the tile
+        for (int i = t + kStreamBlock; i < ext; i += kStreamBlock)
+            prod[e - lo + i] = val[e + i] * x[col_ind[e + i]];
     __syncthreads();
 
     // ---- phase 2b: one lane per owned row, long rows deferred
@@ -420,22 +443,32 @@ hipError_t launch_csr_vector(int lanes_per_row, const int *row_ptr, const int *c
     return hipGetLastError();
 }
 
+static int tile_group()
+{
+    static const int g = [] {
+        const char *e = getenv("SMVP_TILE_GROUP");  // development switch
+        const int v = e ? atoi(e) : kStreamTileGroup;
+        return v >= 1 ? v : 1;
+    }();
+    return g;
+}
+
 hipError_t launch_csr_stream(int vpt, const int *row_ptr, const int *col_ind, const double *val,
                              const double *x, double *y, const int *tile_row, const int *carry_row,
                              double *carry, int rows, int nnz, int ntiles, hipStream_t stream)
 {
     if (rows <= 0)
         return hipSuccess;
-    const int tiles_per_xcd = (ntiles + 7) / 8;
-    const dim3 grid((unsigned)tiles_per_xcd * 8u);
+    const int group = tile_group();
+    const dim3 grid((unsigned)((ntiles + 8 * group - 1) / (8 * group)) * 8u * group);
     switch (vpt) {
     case 4:
         hipLaunchKernelGGL(csr_stream_tiles<4>, grid, dim3(kStreamBlock), 0, stream, row_ptr, col_ind, val, x, y,
-                           tile_row, carry, rows, nnz, ntiles, tiles_per_xcd);
+                           tile_row, carry, rows, nnz, ntiles, group);
         break;
     case 8:
         hipLaunchKernelGGL(csr_stream_tiles<8>, grid, dim3(kStreamBlock), 0, stream, row_ptr, col_ind, val, x, y,
-                           tile_row, carry, rows, nnz, ntiles, tiles_per_xcd);
+                           tile_row, carry, rows, nnz, ntiles, group);
         break;
     default:
         return hipErrorInvalidValue;
@@ -457,16 +490,16 @@ hipError_t launch_csr_stream_owner(int vpt, const int *row_ptr, const int *col_i
 {
     if (rows <= 0)
         return hipSuccess;
-    const int tiles_per_xcd = (ntiles + 7) / 8;
-    const dim3 grid((unsigned)tiles_per_xcd * 8u);
+    const int group = tile_group();
+    const dim3 grid((unsigned)((ntiles + 8 * group - 1) / (8 * group)) * 8u * group);
     switch (vpt) {
     case 4:
         hipLaunchKernelGGL(csr_stream_owner<4>, grid, dim3(kStreamBlock), 0, stream, row_ptr, col_ind, val, x, y,
-                           tile_row, tile_next, rows, nnz, ntiles, tiles_per_xcd);
+                           tile_row, tile_next, rows, nnz, ntiles, group);
         break;
     case 8:
         hipLaunchKernelGGL(csr_stream_owner<8>, grid, dim3(kStreamBlock), 0, stream, row_ptr, col_ind, val, x, y,
-                           tile_row, tile_next, rows, nnz, ntiles, tiles_per_xcd);
+                           tile_row, tile_next, rows, nnz, ntiles, group);
         break;
     default:
         return hipErrorInvalidValue;
