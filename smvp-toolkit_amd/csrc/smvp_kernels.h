@@ -8,7 +8,7 @@ constexpr int kVectorBlock = 256;   // threads per block, csr_vector_rows
 constexpr int kStreamBlock = 256;   // threads per block, csr_stream_tiles
 constexpr int kLongRow = 32;        // segments longer than this are summed by a wavefront
 constexpr int kStreamOver = 1024;    // entries past its end a tile may finish its last row with, through LDS
-constexpr int kStreamTileGroup = 1;   // consecutive tiles per XCD turn (see tile_of_block)
+constexpr int kStreamTileGroup = 64;  // consecutive tiles per XCD turn (see tile_of_block)
 constexpr int kTjdsBlock = 256;     // permuted columns per work item
 constexpr int kTjdsDiagChunk = 8;   // jagged diagonals per work item
 

@@ -31,10 +31,15 @@ __device__ __forceinline__ double shfl_down_sum(double v)
 
 // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Tiles are
 // handed out in groups: XCD i takes `group` consecutive tiles out of every run of
-// 8*group, so an XCD's L2 sees neighbouring rows (and their near-diagonal x) while
-// all eight XCDs stay within 8*group tiles of each other in memory.  group = 1 is
-// the plain order.  Measured on MI355X (memplus x944 / pwt x459, % of HBM peak):
-// whole-matrix-per-XCD runs 60.1 / 64.4, plain order 63.8 / 71.2.
+// 8*group, so an XCD's L2 sees neighbouring rows (and re-uses their x lines) while
+// all eight XCDs stay within 8*group tiles of each other in memory.  Measured on
+// MI355X (profiles/r01_tile_group_sweep.txt; % of HBM peak on memplus x944 / on the
+// random model, L2->fabric read bytes per launch):
+//   group 1     64.9 / 18.7   2.08 GB      group 128   64.4 / 21.8   1.68 GB
+//   group 8     65.5 / 19.3   1.91 GB      group 512   62.2 / 21.7   1.61 GB
+//   group 32    65.2 / 21.2   1.84 GB      group 2048  55.9 / 20.8   1.60 GB
+// (one XCD per contiguous eighth of the matrix was 60.1 %).  64 keeps the speed of
+// the small groups and most of the traffic saving of the large ones.
 // Speed only: any placement gives the same result.
 __device__ __forceinline__ int tile_of_block(int block, int group)
 {
