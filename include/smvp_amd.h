@@ -184,7 +184,6 @@ typedef struct smvp_run_opts {
     int csr_kernel;     /* SMVP_CSR_KERNEL_* */
     int csr_param;      /* 0 = default */
     int tjds_ref_quirks;/* 1: reproduce the reference's defective TJDS output */
-    int use_graph;      /* 1: replay the product from a hipGraph (per-iteration timing kept) */
     const double *x;    /* host operand, NULL = all ones (main-cli.c:368-369) */
 } smvp_run_opts_t;
 void smvp_run_opts_default(smvp_run_opts_t *o);

@@ -32,7 +32,7 @@ class TimeStats(C.Structure):
 
 class RunOpts(C.Structure):
     _fields_ = [("device", C.c_int), ("csr_kernel", C.c_int), ("csr_param", C.c_int),
-                ("tjds_ref_quirks", C.c_int), ("use_graph", C.c_int), ("x", C.c_void_p)]
+                ("tjds_ref_quirks", C.c_int), ("x", C.c_void_p)]
 
 
 class SmvpError(RuntimeError):
