@@ -302,8 +302,10 @@ def main():
             coo = np.zeros(blk["nnz"], dtype=sm.COO_DTYPE)
             coo["row"] = np.repeat(np.arange(blk["rows"], dtype=np.int32), np.diff(blk["row_ptr"]))
             coo["col"], coo["val"] = blk["col_ind"], blk["val"]
-            tj = sm.tjds_from_coo(coo, blk["rows"], blk["cols_total"])
+            d_coo = torch.from_numpy(coo.view(np.uint8)).cuda()
             del coo
+            tj = sm.tjds_from_coo_device(d_coo, blk["rows"], blk["cols_total"], blk["nnz"])   # radix sort + scans on the GPU
+            del d_coo
             T = sm.TjdsMatrix(tj, device=local_rank)
             tname, tbytes = T.describe()
             log(rank, "TJDS built in %.1f s: %d jagged diagonals" % (time.perf_counter() - t0, tj.num_diag))

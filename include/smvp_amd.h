@@ -117,6 +117,17 @@ int smvp_tjds_from_coo(const smvp_coo_t *coo, int rows, int cols, int nnz,
                        int *row_ind, double *val,
                        int *num_diag, int *ref_num_tjdiag, int *last_diag_single);
 
+/* The same two conversions on the GPU (next row of SURVEY 8(f)): every pointer is a device
+ * address, outputs are bit-identical to the host versions above.  Radix sort + scans instead of
+ * the reference's qsorts and its O(nnz * cols) renumbering (main-cli.c:894-904).  Both return
+ * after the work on `stream` has finished. */
+int smvp_csr_from_coo_device(const smvp_coo_t *d_coo, int rows, int cols, int nnz,
+                             int *d_row_ptr, int *d_col_ind, double *d_val, void *stream);
+int smvp_tjds_from_coo_device(const smvp_coo_t *d_coo, int rows, int cols, int nnz,
+                              int *d_perm, int *d_start_pos, int start_pos_capacity,
+                              int *d_row_ind, double *d_val,
+                              int *num_diag, int *ref_num_tjdiag, int *last_diag_single, void *stream);
+
 /* ---------------------------------------------------------- device / engine */
 int smvp_device_count(int *count);
 int smvp_device_info(int device, char *name, size_t name_cap, int *compute_units,
@@ -184,6 +195,7 @@ typedef struct smvp_run_opts {
     int csr_kernel;     /* SMVP_CSR_KERNEL_* */
     int csr_param;      /* 0 = default */
     int tjds_ref_quirks;/* 1: reproduce the reference's defective TJDS output */
+    int convert_on_device; /* 1: COO -> CSR / TJDS on the GPU (smvp_*_from_coo_device), 0: on the host */
     const double *x;    /* host operand, NULL = all ones (main-cli.c:368-369) */
 } smvp_run_opts_t;
 void smvp_run_opts_default(smvp_run_opts_t *o);

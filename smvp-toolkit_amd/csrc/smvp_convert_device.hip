@@ -1,0 +1,322 @@
+// smvp_convert_device.hip -- COO -> CSR and COO -> TJDS on the GPU.
+//
+// Same outputs, bit for bit, as the host converters in smvp_convert.cpp (and so
+// as the reference's main-cli.c:340-365 and :766-967), for inputs that are
+// already in HBM or too large to convert comfortably on one host thread: the
+// reference's own TJDS build is O(nnz * cols) (main-cli.c:894-904), the host
+// converter here takes 15 s for 119 M entries, this path tens of milliseconds.
+//
+// The heavy lifting is two stable LSD radix sorts (rocPRIM device primitives --
+// setup work, not the timed product) on keys packed as major * 2^bits(minor) + minor,
+// with the entry's input position as the value, so ties keep input order exactly
+// like the host's stable counting sorts.
+#include "smvp_common.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return smvp::fail(SMVP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+
+typedef unsigned long long u64;
+
+// Frees everything it handed out when it goes out of scope.
+struct Scratch {
+    std::vector<void *> ptrs;
+    ~Scratch()
+    {
+        for (void *p : ptrs)
+            (void)hipFree(p);
+    }
+    template <class T>
+    hipError_t get(T **out, size_t count)
+    {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(count, 4) * sizeof(T));
+        if (e == hipSuccess)
+            ptrs.push_back(p);
+        *out = (T *)p;
+        return e;
+    }
+};
+
+int bits_for(int n)  // bits needed for values 0 .. n-1
+{
+    int b = 1;
+    while (b < 31 && (1ll << b) < n)
+        ++b;
+    return b;
+}
+
+__global__ __launch_bounds__(256) void pack_keys(const smvp_coo_t *__restrict__ coo, int nnz, int rows, int cols,
+                                                 int minor_bits, bool row_major, u64 *__restrict__ keys,
+                                                 unsigned *__restrict__ idx, int *__restrict__ major_count,
+                                                 int *__restrict__ bad)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nnz)
+        return;
+    const int r = coo[i].row, c = coo[i].col;
+    if (r < 0 || r >= rows || c < 0 || c >= cols) {
+        atomicExch(bad, i + 1);
+        keys[i] = 0;
+        idx[i] = (unsigned)i;
+        return;
+    }
+    const int major = row_major ? r : c, minor = row_major ? c : r;
+    keys[i] = ((u64)(unsigned)major << minor_bits) | (u64)(unsigned)minor;
+    idx[i] = (unsigned)i;
+    atomicAdd(&major_count[major], 1);
+}
+
+__global__ __launch_bounds__(256) void gather_csr(const smvp_coo_t *__restrict__ coo, const unsigned *__restrict__ order,
+                                                  int nnz, int *__restrict__ col_ind, double *__restrict__ val)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nnz)
+        return;
+    const smvp_coo_t e = coo[order[t]];
+    col_ind[t] = e.col;
+    val[t] = e.val;
+}
+
+__global__ __launch_bounds__(256) void column_lengths(const int *__restrict__ start, int cols, int *__restrict__ len)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < cols)
+        len[c] = start[c + 1] - start[c];
+}
+
+__global__ __launch_bounds__(256) void length_keys(const int *__restrict__ col_len, int cols, unsigned *__restrict__ key,
+                                                   unsigned *__restrict__ col)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols)
+        return;
+    key[c] = 0x7fffffffu - (unsigned)col_len[c];  // ascending key == descending length
+    col[c] = (unsigned)c;
+}
+
+__global__ __launch_bounds__(256) void invert_perm(const unsigned *__restrict__ perm_u, int cols, int *__restrict__ perm,
+                                                   int *__restrict__ where)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= cols)
+        return;
+    const int c = (int)perm_u[k];
+    perm[k] = c;
+    where[c] = k;
+}
+
+// width[d] = number of columns longer than d = first k with len_sorted[k] <= d (lengths never increase with k)
+__global__ __launch_bounds__(256) void diagonal_widths(const unsigned *__restrict__ len_key_sorted, int cols, int longest,
+                                                       int *__restrict__ width)
+{
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d > longest)
+        return;
+    if (d == longest) {
+        width[d] = 0;
+        return;
+    }
+    int lo = 0, hi = cols;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int len = (int)(0x7fffffffu - len_key_sorted[mid]);
+        if (len > d)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    width[d] = lo;
+}
+
+__global__ __launch_bounds__(256) void scatter_tjds(const smvp_coo_t *__restrict__ coo, const unsigned *__restrict__ order,
+                                                    int nnz, const int *__restrict__ col_start,
+                                                    const int *__restrict__ where, const int *__restrict__ start_pos,
+                                                    int *__restrict__ row_ind, double *__restrict__ val)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nnz)
+        return;
+    const smvp_coo_t e = coo[order[t]];
+    const int d = t - col_start[e.col];  // rank inside the column == jagged-diagonal number
+    const int j = start_pos[d] + where[e.col];
+    row_ind[j] = e.row;
+    val[j] = e.val;
+}
+
+inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
+
+// order[] = input positions sorted by (major, minor), ties in input order; major_start[] = exclusive scan of counts
+int sort_entries(Scratch &sc, const smvp_coo_t *d_coo, int rows, int cols, int nnz, bool row_major, hipStream_t st,
+                 unsigned **order_out, int **major_start_out)
+{
+    const int n_major = row_major ? rows : cols, n_minor = row_major ? cols : rows;
+    const int minor_bits = bits_for(n_minor), major_bits = bits_for(n_major);
+    u64 *k0, *k1;
+    unsigned *i0, *i1;
+    int *count, *start, *bad;
+    HIP_TRY(sc.get(&k0, (size_t)nnz));
+    HIP_TRY(sc.get(&k1, (size_t)nnz));
+    HIP_TRY(sc.get(&i0, (size_t)nnz));
+    HIP_TRY(sc.get(&i1, (size_t)nnz));
+    HIP_TRY(sc.get(&count, (size_t)n_major + 1));
+    HIP_TRY(sc.get(&start, (size_t)n_major + 1));
+    HIP_TRY(sc.get(&bad, 1));
+    HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * ((size_t)n_major + 1), st));
+    HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), st));
+    if (nnz > 0) {
+        hipLaunchKernelGGL(pack_keys, dim3(blocks_for(nnz)), dim3(256), 0, st, d_coo, nnz, rows, cols, minor_bits,
+                           row_major, k0, i0, count, bad);
+        HIP_TRY(hipGetLastError());
+        size_t tmp_bytes = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, i0, i1, (size_t)nnz, 0u,
+                                          (unsigned)(minor_bits + major_bits), st));
+        char *tmp;
+        HIP_TRY(sc.get(&tmp, tmp_bytes));
+        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, i0, i1, (size_t)nnz, 0u,
+                                          (unsigned)(minor_bits + major_bits), st));
+    }
+    {
+        size_t tmp_bytes = 0;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, count, start, 0, (size_t)n_major + 1, rocprim::plus<int>(), st));
+        char *tmp;
+        HIP_TRY(sc.get(&tmp, tmp_bytes));
+        HIP_TRY(rocprim::exclusive_scan(tmp, tmp_bytes, count, start, 0, (size_t)n_major + 1, rocprim::plus<int>(), st));
+    }
+    int h_bad = 0;
+    HIP_TRY(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h_bad)
+        return smvp::fail(SMVP_ERR_INVALID, "device conversion: entry %d lies outside %d x %d", h_bad - 1, rows, cols);
+    *order_out = i1;
+    *major_start_out = start;
+    return SMVP_OK;
+}
+
+int check_device(const void *p, const char *who)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return smvp::fail(SMVP_ERR_NO_DEVICE, "%s: no HIP device is visible", who);
+    (void)p;
+    return SMVP_OK;
+}
+
+}  // namespace
+
+extern "C" int smvp_csr_from_coo_device(const smvp_coo_t *d_coo, int rows, int cols, int nnz,
+                                        int *d_row_ptr, int *d_col_ind, double *d_val, void *stream)
+{
+    if (rows < 0 || cols < 0 || nnz < 0 || !d_row_ptr || (nnz > 0 && (!d_coo || !d_col_ind || !d_val)))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_from_coo_device: bad argument");
+    if (nnz > 0 && (rows == 0 || cols == 0))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_from_coo_device: entries in an empty matrix");
+    if (int rc = check_device(d_coo, "smvp_csr_from_coo_device"))
+        return rc;
+    hipStream_t st = (hipStream_t)stream;
+    Scratch sc;
+    unsigned *order = nullptr;
+    int *row_start = nullptr;
+    if (int rc = sort_entries(sc, d_coo, rows, std::max(cols, 1), nnz, true, st, &order, &row_start))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(d_row_ptr, row_start, sizeof(int) * ((size_t)rows + 1), hipMemcpyDeviceToDevice, st));
+    if (nnz > 0) {
+        hipLaunchKernelGGL(gather_csr, dim3(blocks_for(nnz)), dim3(256), 0, st, d_coo, order, nnz, d_col_ind, d_val);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return SMVP_OK;
+}
+
+extern "C" int smvp_tjds_from_coo_device(const smvp_coo_t *d_coo, int rows, int cols, int nnz,
+                                         int *d_perm, int *d_start_pos, int start_pos_capacity,
+                                         int *d_row_ind, double *d_val,
+                                         int *num_diag, int *ref_num_tjdiag, int *last_diag_single, void *stream)
+{
+    if (rows < 0 || cols < 0 || nnz < 0 || !d_start_pos || !num_diag || (cols > 0 && !d_perm) ||
+        (nnz > 0 && (!d_coo || !d_row_ind || !d_val)))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_from_coo_device: bad argument");
+    if (nnz > 0 && (rows == 0 || cols == 0))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_from_coo_device: entries in an empty matrix");
+    if (int rc = check_device(d_coo, "smvp_tjds_from_coo_device"))
+        return rc;
+    hipStream_t st = (hipStream_t)stream;
+    Scratch sc;
+    unsigned *order = nullptr;
+    int *col_start = nullptr;  // cols + 1 entries; col_start[c+1] - col_start[c] = length of column c
+    if (int rc = sort_entries(sc, d_coo, std::max(rows, 1), cols, nnz, false, st, &order, &col_start))
+        return rc;
+
+    // column lengths, then the permutation: one stable sort on (longest-first) length keys
+    int *col_len, *where, *width;
+    unsigned *lk0, *lk1, *lc0, *lc1;
+    HIP_TRY(sc.get(&col_len, (size_t)cols + 1));
+    HIP_TRY(sc.get(&where, (size_t)cols + 1));
+    HIP_TRY(sc.get(&lk0, (size_t)cols));
+    HIP_TRY(sc.get(&lk1, (size_t)cols));
+    HIP_TRY(sc.get(&lc0, (size_t)cols));
+    HIP_TRY(sc.get(&lc1, (size_t)cols));
+    int longest = 0, len0 = 0;
+    if (cols > 0) {
+        hipLaunchKernelGGL(column_lengths, dim3(blocks_for(cols)), dim3(256), 0, st, col_start, cols, col_len);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(length_keys, dim3(blocks_for(cols)), dim3(256), 0, st, col_len, cols, lk0, lc0);
+        HIP_TRY(hipGetLastError());
+        size_t tmp_bytes = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, lk0, lk1, lc0, lc1, (size_t)cols, 0u, 32u, st));
+        char *tmp;
+        HIP_TRY(sc.get(&tmp, tmp_bytes));
+        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, lk0, lk1, lc0, lc1, (size_t)cols, 0u, 32u, st));
+        hipLaunchKernelGGL(invert_perm, dim3(blocks_for(cols)), dim3(256), 0, st, lc1, cols, d_perm, where);
+        HIP_TRY(hipGetLastError());
+        unsigned first_key = 0;
+        HIP_TRY(hipMemcpyAsync(&first_key, lk1, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&len0, col_len, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        longest = (int)(0x7fffffffu - first_key);
+    }
+    if (longest + 1 > start_pos_capacity)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_from_coo_device: %d diagonals need start_pos_capacity >= %d",
+                          longest, longest + 1);
+
+    // start_pos = exclusive scan of the diagonal widths; start_pos[longest] = nnz falls out of the scan
+    HIP_TRY(sc.get(&width, (size_t)longest + 1));
+    hipLaunchKernelGGL(diagonal_widths, dim3(blocks_for(longest + 1)), dim3(256), 0, st, lk1, cols, longest, width);
+    HIP_TRY(hipGetLastError());
+    {
+        size_t tmp_bytes = 0;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, width, d_start_pos, 0, (size_t)longest + 1, rocprim::plus<int>(), st));
+        char *tmp;
+        HIP_TRY(sc.get(&tmp, tmp_bytes));
+        HIP_TRY(rocprim::exclusive_scan(tmp, tmp_bytes, width, d_start_pos, 0, (size_t)longest + 1, rocprim::plus<int>(), st));
+    }
+    if (nnz > 0) {
+        hipLaunchKernelGGL(scatter_tjds, dim3(blocks_for(nnz)), dim3(256), 0, st, d_coo, order, nnz, col_start, where,
+                           d_start_pos, d_row_ind, d_val);
+        HIP_TRY(hipGetLastError());
+    }
+    int last_width = 0;
+    if (longest > 0)
+        HIP_TRY(hipMemcpyAsync(&last_width, width + longest - 1, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *num_diag = longest;
+    if (ref_num_tjdiag)
+        *ref_num_tjdiag = cols > 0 ? len0 : 0;
+    if (last_diag_single)
+        *last_diag_single = (longest > 0 && last_width == 1) ? 1 : 0;
+    return SMVP_OK;
+}

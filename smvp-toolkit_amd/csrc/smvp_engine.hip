@@ -579,6 +579,9 @@ namespace {
 // Scope guard for the scratch the two entry points allocate.
 struct RunScratch {
     double *d_x = nullptr, *d_y = nullptr;
+    void *d_coo = nullptr;                               // convert_on_device: the uploaded COO
+    int *d_i0 = nullptr, *d_i1 = nullptr, *d_i2 = nullptr;  // ... and the arrays built from it
+    double *d_v = nullptr;
     std::vector<hipEvent_t> ev;
     hipStream_t stream = nullptr;
     smvp_csr_t *csr = nullptr;
@@ -595,6 +598,9 @@ struct RunScratch {
             (void)hipStreamDestroy(stream);
         smvp_csr_destroy(csr);
         smvp_tjds_destroy(tjds);
+        for (void *p : {d_coo, (void *)d_i0, (void *)d_i1, (void *)d_i2, (void *)d_v})
+            if (p)
+                (void)hipFree(p);
     }
 };
 
@@ -654,15 +660,28 @@ extern "C" int smvp_csr_compute(const smvp_coo_t *coo, int rows, int cols, int n
         return rc;
     HIP_TRY(hipSetDevice(o->device));
 
-    std::vector<int> row_ptr((size_t)rows + 1), col_ind((size_t)std::max(nnz, 1));
-    std::vector<double> val((size_t)std::max(nnz, 1));
-    if (int rc = smvp_csr_from_coo(coo, rows, nnz, row_ptr.data(), col_ind.data(), val.data()))
-        return rc;
-
     RunScratch s;
-    if (int rc = smvp_csr_create(&s.csr, o->device, rows, cols, nnz, row_ptr.data(), col_ind.data(), val.data(),
-                                 SMVP_MEM_HOST, nullptr))
-        return rc;
+    if (o->convert_on_device) {
+        // COO goes to HBM as it is; sort + scan there; the arrays stay where they were built
+        HIP_TRY(hipMalloc(&s.d_coo, sizeof(smvp_coo_t) * (size_t)std::max(nnz, 1)));
+        HIP_TRY(hipMalloc((void **)&s.d_i0, sizeof(int) * ((size_t)rows + 1)));
+        HIP_TRY(hipMalloc((void **)&s.d_i1, sizeof(int) * (size_t)std::max(nnz, 1)));
+        HIP_TRY(hipMalloc((void **)&s.d_v, sizeof(double) * (size_t)std::max(nnz, 1)));
+        if (nnz > 0)
+            HIP_TRY(hipMemcpy(s.d_coo, coo, sizeof(smvp_coo_t) * (size_t)nnz, hipMemcpyHostToDevice));
+        if (int rc = smvp_csr_from_coo_device((const smvp_coo_t *)s.d_coo, rows, cols, nnz, s.d_i0, s.d_i1, s.d_v, nullptr))
+            return rc;
+        if (int rc = smvp_csr_create(&s.csr, o->device, rows, cols, nnz, s.d_i0, s.d_i1, s.d_v, SMVP_MEM_DEVICE, nullptr))
+            return rc;
+    } else {
+        std::vector<int> row_ptr((size_t)rows + 1), col_ind((size_t)std::max(nnz, 1));
+        std::vector<double> val((size_t)std::max(nnz, 1));
+        if (int rc = smvp_csr_from_coo(coo, rows, nnz, row_ptr.data(), col_ind.data(), val.data()))
+            return rc;
+        if (int rc = smvp_csr_create(&s.csr, o->device, rows, cols, nnz, row_ptr.data(), col_ind.data(), val.data(),
+                                     SMVP_MEM_HOST, nullptr))
+            return rc;
+    }
     if (o->csr_kernel != SMVP_CSR_KERNEL_AUTO || o->csr_param != 0)
         if (int rc = smvp_csr_set_kernel(s.csr, o->csr_kernel, o->csr_param))
             return rc;
@@ -695,18 +714,34 @@ extern "C" int smvp_tjds_compute(const smvp_coo_t *coo, int rows, int cols, int 
         return rc;
     HIP_TRY(hipSetDevice(o->device));
 
-    std::vector<int> perm((size_t)std::max(cols, 1)), start_pos((size_t)std::max(rows, nnz) + 2),
-        row_ind((size_t)std::max(nnz, 1));
-    std::vector<double> val((size_t)std::max(nnz, 1));
     int num_diag = 0, ref_num = 0, last_single = 0;
-    if (int rc = smvp_tjds_from_coo(coo, rows, cols, nnz, perm.data(), start_pos.data(), (int)start_pos.size(),
-                                    row_ind.data(), val.data(), &num_diag, &ref_num, &last_single))
-        return rc;
-
     RunScratch s;
-    if (int rc = smvp_tjds_create(&s.tjds, o->device, rows, cols, nnz, num_diag, perm.data(), start_pos.data(),
-                                  row_ind.data(), val.data(), SMVP_MEM_HOST))
-        return rc;
+    if (o->convert_on_device) {
+        const int cap = std::max(rows, nnz) + 2;
+        HIP_TRY(hipMalloc(&s.d_coo, sizeof(smvp_coo_t) * (size_t)std::max(nnz, 1)));
+        HIP_TRY(hipMalloc((void **)&s.d_i0, sizeof(int) * (size_t)std::max(cols, 1)));   // perm
+        HIP_TRY(hipMalloc((void **)&s.d_i1, sizeof(int) * (size_t)std::max(nnz, 1)));    // row_ind
+        HIP_TRY(hipMalloc((void **)&s.d_i2, sizeof(int) * (size_t)cap));                 // start_pos
+        HIP_TRY(hipMalloc((void **)&s.d_v, sizeof(double) * (size_t)std::max(nnz, 1)));
+        if (nnz > 0)
+            HIP_TRY(hipMemcpy(s.d_coo, coo, sizeof(smvp_coo_t) * (size_t)nnz, hipMemcpyHostToDevice));
+        if (int rc = smvp_tjds_from_coo_device((const smvp_coo_t *)s.d_coo, rows, cols, nnz, s.d_i0, s.d_i2, cap, s.d_i1,
+                                               s.d_v, &num_diag, &ref_num, &last_single, nullptr))
+            return rc;
+        if (int rc = smvp_tjds_create(&s.tjds, o->device, rows, cols, nnz, num_diag, s.d_i0, s.d_i2, s.d_i1, s.d_v,
+                                      SMVP_MEM_DEVICE))
+            return rc;
+    } else {
+        std::vector<int> perm((size_t)std::max(cols, 1)), start_pos((size_t)std::max(rows, nnz) + 2),
+            row_ind((size_t)std::max(nnz, 1));
+        std::vector<double> val((size_t)std::max(nnz, 1));
+        if (int rc = smvp_tjds_from_coo(coo, rows, cols, nnz, perm.data(), start_pos.data(), (int)start_pos.size(),
+                                        row_ind.data(), val.data(), &num_diag, &ref_num, &last_single))
+            return rc;
+        if (int rc = smvp_tjds_create(&s.tjds, o->device, rows, cols, nnz, num_diag, perm.data(), start_pos.data(),
+                                      row_ind.data(), val.data(), SMVP_MEM_HOST))
+            return rc;
+    }
     if (o->tjds_ref_quirks)
         if (int rc = smvp_tjds_set_ref_quirks(s.tjds, 1, ref_num, last_single))
             return rc;

@@ -32,7 +32,7 @@ class TimeStats(C.Structure):
 
 class RunOpts(C.Structure):
     _fields_ = [("device", C.c_int), ("csr_kernel", C.c_int), ("csr_param", C.c_int),
-                ("tjds_ref_quirks", C.c_int), ("x", C.c_void_p)]
+                ("tjds_ref_quirks", C.c_int), ("convert_on_device", C.c_int), ("x", C.c_void_p)]
 
 
 class SmvpError(RuntimeError):
@@ -49,7 +49,7 @@ EXPORTS = [
     "smvp_last_error", "smvp_version_string",
     "smvp_mm_read_banner", "smvp_mm_read_mtx_crd_size", "smvp_mm_read_coo_entries",
     "smvp_mm_read_header_path", "smvp_mm_read_coo_path",
-    "smvp_csr_from_coo", "smvp_tjds_from_coo",
+    "smvp_csr_from_coo", "smvp_tjds_from_coo", "smvp_csr_from_coo_device", "smvp_tjds_from_coo_device",
     "smvp_device_count", "smvp_device_info",
     "smvp_csr_create", "smvp_csr_set_kernel", "smvp_csr_get_kernel", "smvp_csr_spmv",
     "smvp_csr_describe", "smvp_csr_destroy",
@@ -89,6 +89,9 @@ def lib():
         L.smvp_tjds_destroy.restype = None
         L.smvp_csr_from_coo.argtypes = [vp, ci, ci, vp, vp, vp]
         L.smvp_tjds_from_coo.argtypes = [vp, ci, ci, ci, vp, vp, ci, vp, vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+        L.smvp_csr_from_coo_device.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
+        L.smvp_tjds_from_coo_device.argtypes = [vp, ci, ci, ci, vp, vp, ci, vp, vp, C.POINTER(ci), C.POINTER(ci),
+                                                C.POINTER(ci), vp]
         L.smvp_csr_compute.argtypes = [vp, ci, ci, ci, ci, C.POINTER(RunOpts), vp, vp, C.POINTER(TimeStats)]
         L.smvp_tjds_compute.argtypes = [vp, ci, ci, ci, ci, C.POINTER(RunOpts), vp, vp, C.POINTER(TimeStats)]
         L.smvp_run_opts_default.argtypes = [C.POINTER(RunOpts)]
@@ -180,6 +183,40 @@ def tjds_from_coo(coo, rows, cols):
                                     _p(val), C.byref(nd), C.byref(rn), C.byref(ls)), "smvp_tjds_from_coo")
     t.num_diag, t.ref_num_tjdiag, t.last_diag_single = nd.value, rn.value, ls.value
     t.perm, t.start_pos = perm[:cols], sp[:t.num_diag + 1].copy()
+    t.row_ind, t.val = row_ind[:nnz], val[:nnz]
+    return t
+
+
+def csr_from_coo_device(d_coo, rows, cols, nnz, stream=None):
+    """COO -> CSR on the GPU.  d_coo: torch uint8 CUDA tensor holding nnz smvp_coo_t (16 B each).
+    Returns (row_ptr, col_ind, val) as torch CUDA tensors."""
+    import torch
+
+    row_ptr = torch.empty(rows + 1, dtype=torch.int32, device=d_coo.device)
+    col_ind = torch.empty(max(nnz, 1), dtype=torch.int32, device=d_coo.device)
+    val = torch.empty(max(nnz, 1), dtype=torch.float64, device=d_coo.device)
+    _check(lib().smvp_csr_from_coo_device(_dev_ptr(d_coo), rows, cols, nnz, _dev_ptr(row_ptr), _dev_ptr(col_ind),
+                                          _dev_ptr(val), _stream_ptr(stream)), "smvp_csr_from_coo_device")
+    return row_ptr, col_ind[:nnz], val[:nnz]
+
+
+def tjds_from_coo_device(d_coo, rows, cols, nnz, stream=None):
+    """COO -> TJDS on the GPU -> TjdsArrays whose arrays are torch CUDA tensors."""
+    import torch
+
+    t = TjdsArrays()
+    t.rows, t.cols, t.nnz = rows, cols, nnz
+    cap = max(rows, nnz) + 2
+    perm = torch.empty(max(cols, 1), dtype=torch.int32, device=d_coo.device)
+    sp = torch.empty(cap, dtype=torch.int32, device=d_coo.device)
+    row_ind = torch.empty(max(nnz, 1), dtype=torch.int32, device=d_coo.device)
+    val = torch.empty(max(nnz, 1), dtype=torch.float64, device=d_coo.device)
+    nd, rn, ls = C.c_int(), C.c_int(), C.c_int()
+    _check(lib().smvp_tjds_from_coo_device(_dev_ptr(d_coo), rows, cols, nnz, _dev_ptr(perm), _dev_ptr(sp), cap,
+                                           _dev_ptr(row_ind), _dev_ptr(val), C.byref(nd), C.byref(rn), C.byref(ls),
+                                           _stream_ptr(stream)), "smvp_tjds_from_coo_device")
+    t.num_diag, t.ref_num_tjdiag, t.last_diag_single = nd.value, rn.value, ls.value
+    t.perm, t.start_pos = perm[:cols], sp[:t.num_diag + 1]
     t.row_ind, t.val = row_ind[:nnz], val[:nnz]
     return t
 
@@ -302,10 +339,15 @@ class TjdsMatrix:
         self.rows, self.cols, self.nnz = t.rows, t.cols, t.nnz
         self._t = t
         self._h = C.c_void_p()
-        _check(lib().smvp_tjds_create(C.byref(self._h), device, t.rows, t.cols, t.nnz, t.num_diag,
-                                      _p(_arr(t.perm, np.int32)), _p(_arr(t.start_pos, np.int32)),
-                                      _p(_arr(t.row_ind, np.int32)), _p(_arr(t.val, np.float64)), MEM_HOST),
-               "smvp_tjds_create")
+        if isinstance(t.perm, np.ndarray):
+            _check(lib().smvp_tjds_create(C.byref(self._h), device, t.rows, t.cols, t.nnz, t.num_diag,
+                                          _p(_arr(t.perm, np.int32)), _p(_arr(t.start_pos, np.int32)),
+                                          _p(_arr(t.row_ind, np.int32)), _p(_arr(t.val, np.float64)), MEM_HOST),
+                   "smvp_tjds_create")
+        else:       # torch CUDA tensors (smvp_tjds_from_coo_device): adopted in place
+            _check(lib().smvp_tjds_create(C.byref(self._h), device, t.rows, t.cols, t.nnz, t.num_diag,
+                                          _dev_ptr(t.perm), _dev_ptr(t.start_pos), _dev_ptr(t.row_ind),
+                                          _dev_ptr(t.val), MEM_DEVICE), "smvp_tjds_create")
 
     def set_x(self, x, stream=None):
         _check(lib().smvp_tjds_set_x(self._h, _dev_ptr(x), _stream_ptr(stream)), "smvp_tjds_set_x")
@@ -339,10 +381,11 @@ class TjdsMatrix:
 
 
 # ------------------------------------------------- reference-shaped entry points
-def _run_opts(device, csr_kernel, csr_param, ref_quirks, x):
+def _run_opts(device, csr_kernel, csr_param, ref_quirks, x, device_convert=False):
     o = RunOpts()
     lib().smvp_run_opts_default(C.byref(o))
     o.device, o.csr_kernel, o.csr_param, o.tjds_ref_quirks = device, csr_kernel, csr_param, int(ref_quirks)
+    o.convert_on_device = int(device_convert)
     keep = None
     if x is not None:
         keep = _arr(x, np.float64)
@@ -350,27 +393,27 @@ def _run_opts(device, csr_kernel, csr_param, ref_quirks, x):
     return o, keep
 
 
-def csr_compute(coo, rows, cols, iters=1, device=0, kernel=CSR_KERNEL_AUTO, param=0, x=None):
+def csr_compute(coo, rows, cols, iters=1, device=0, kernel=CSR_KERNEL_AUTO, param=0, x=None, device_convert=False):
     """smvp_csr_compute: COO in, (y, per-iteration ms, TimeStats) out."""
     nnz = len(coo)
     coo = _arr(coo, COO_DTYPE)
     y = np.zeros(max(rows, 1), dtype=np.float64)
     ms = np.zeros(iters, dtype=np.float64)
     st = TimeStats()
-    o, keep = _run_opts(device, kernel, param, False, x)
+    o, keep = _run_opts(device, kernel, param, False, x, device_convert)
     _check(lib().smvp_csr_compute(_p(coo), rows, cols, nnz, iters, C.byref(o), _p(y), _p(ms), C.byref(st)),
            "smvp_csr_compute")
     return y[:rows], ms, st
 
 
-def tjds_compute(coo, rows, cols, iters=1, device=0, ref_quirks=False, x=None):
+def tjds_compute(coo, rows, cols, iters=1, device=0, ref_quirks=False, x=None, device_convert=False):
     """smvp_tjds_compute: COO in, (y, per-iteration ms, TimeStats) out."""
     nnz = len(coo)
     coo = _arr(coo, COO_DTYPE)
     y = np.zeros(max(rows, 1), dtype=np.float64)
     ms = np.zeros(iters, dtype=np.float64)
     st = TimeStats()
-    o, keep = _run_opts(device, CSR_KERNEL_AUTO, 0, ref_quirks, x)
+    o, keep = _run_opts(device, CSR_KERNEL_AUTO, 0, ref_quirks, x, device_convert)
     _check(lib().smvp_tjds_compute(_p(coo), rows, cols, nnz, iters, C.byref(o), _p(y), _p(ms), C.byref(st)),
            "smvp_tjds_compute")
     return y[:rows], ms, st

@@ -446,3 +446,108 @@ def test_bench_script_runs_small(torch):
     assert j["cpu_baseline"]["cores"] == 1 and j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["agrees_with_gpu"]
     assert j["extra"]["full_size_parity"]["y_equals_tiled_reference_memplus_y"]
     assert "error" not in j["extra"]["tjds"] and "error" not in j["extra"]["survey_random_model"]
+
+
+# --------------------------------------------------- device-side format conversion
+def _coo_to_device(torch, coo):
+    raw = np.ascontiguousarray(coo, dtype=sm.COO_DTYPE).view(np.uint8)
+    if raw.size == 0:
+        return torch.zeros(16, dtype=torch.uint8, device="cuda")
+    return torch.from_numpy(raw.copy()).cuda()
+
+
+def _check_device_conversion(torch, coo, rows, cols):
+    d_coo = _coo_to_device(torch, coo)
+    before = d_coo.clone()
+    rp, ci, v = sm.csr_from_coo_device(d_coo, rows, cols, len(coo))
+    hrp, hci, hv = sm.csr_from_coo(coo, rows)
+    assert np.array_equal(rp.cpu().numpy(), hrp)
+    assert np.array_equal(ci.cpu().numpy(), hci)
+    assert v.cpu().numpy().tobytes() == hv.tobytes()
+    t = sm.tjds_from_coo_device(d_coo, rows, cols, len(coo))
+    h = sm.tjds_from_coo(coo, rows, cols)
+    assert (t.num_diag, t.ref_num_tjdiag, t.last_diag_single) == (h.num_diag, h.ref_num_tjdiag, h.last_diag_single)
+    for f in ("perm", "start_pos", "row_ind"):
+        assert np.array_equal(getattr(t, f).cpu().numpy(), getattr(h, f)), f
+    assert t.val.cpu().numpy().tobytes() == h.val.tobytes()
+    assert torch.equal(d_coo, before)          # the input is not modified
+    return t
+
+
+@pytest.mark.parametrize("name", SAMPLES)
+def test_device_conversion_sample_matrices(torch, name):
+    m, n, coo = load(name)
+    _check_device_conversion(torch, coo, m, n)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_device_conversion_random(torch, seed):
+    rng = np.random.default_rng(100 + seed)
+    rows, cols = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+    nnz = int(rng.integers(0, min(rows * cols, 5000) + 1))
+    flat = rng.choice(rows * cols, size=nnz, replace=False)
+    r, c = flat // cols, flat % cols
+    if seed % 2:                                  # leave some rows and columns empty
+        keep = ((r % 3) != 1) & ((c % 5) != 2)
+        r, c = r[keep], c[keep]
+    coo = sm.make_coo(r, c, rng.uniform(-1, 1, len(r)))
+    _check_device_conversion(torch, coo, rows, cols)
+
+
+def test_device_conversion_edge_cases(torch):
+    _check_device_conversion(torch, sm.make_coo([], [], []), 5, 7)                       # no entries
+    _check_device_conversion(torch, sm.make_coo([0], [0], [2.5]), 1, 1)
+    _check_device_conversion(torch, sm.make_coo([3, 3, 3, 0], [0, 0, 0, 0], [1.0, 2.0, 3.0, 4.0]), 4, 2)  # duplicates keep input order
+    with pytest.raises(sm.SmvpError):
+        sm.csr_from_coo_device(_coo_to_device(torch, sm.make_coo([9], [0], [1.0])), 3, 3, 1)
+    with pytest.raises(sm.SmvpError):
+        sm.tjds_from_coo_device(_coo_to_device(torch, sm.make_coo([0], [-1], [1.0])), 3, 3, 1)
+
+
+def test_device_conversion_large_and_product(torch):
+    """2^20-row memplus-shaped matrix, entries shuffled: device-built CSR and TJDS feed the kernels directly."""
+    M = 1 << 20
+    row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_MEMPLUS_SHAPED, 777, M, M)
+    coo = sm.make_coo(np.repeat(np.arange(M), np.diff(row_ptr)), col_ind, val)
+    coo = coo[np.random.default_rng(5).permutation(len(coo))]
+    d_coo = _coo_to_device(torch, coo)
+    rp, ci, v = sm.csr_from_coo_device(d_coo, M, M, len(coo))
+    assert np.array_equal(rp.cpu().numpy(), row_ptr) and np.array_equal(ci.cpu().numpy(), col_ind)
+    assert v.cpu().numpy().tobytes() == val.tobytes()
+    A = sm.CsrMatrix(M, M, rp, ci, v)
+    x = np.random.default_rng(6).random(M)
+    dx = dev(torch, x)
+    dy = torch.empty(M, dtype=torch.float64, device="cuda")
+    A.spmv(dx, dy)
+    torch.cuda.synchronize()
+    scale = np.add.reduceat(np.abs(val * x[col_ind]), row_ptr[:-1])
+    host = np.add.reduceat(val * x[col_ind], row_ptr[:-1])
+    assert np.all(np.abs(dy.cpu().numpy() - host) <= TOL * scale)
+    t = sm.tjds_from_coo_device(d_coo, M, M, len(coo))
+    h = sm.tjds_from_coo(coo, M, M)
+    for f in ("perm", "start_pos", "row_ind"):
+        assert np.array_equal(getattr(t, f).cpu().numpy(), getattr(h, f)), f
+    assert t.val.cpu().numpy().tobytes() == h.val.tobytes()
+
+
+@pytest.mark.parametrize("name", ["ibm32.mtx", "memplus.mtx", "pwt.mtx"])
+def test_entry_points_with_device_conversion(torch, name):
+    m, n, coo = load(name)
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, np.ones(n))
+    scale = row_scale(row_ptr, col_ind, val, np.ones(n))
+    y, ms, st = sm.csr_compute(coo, m, n, iters=3, device_convert=True)
+    assert_close(y, ref, scale, exact=name in EXACT)
+    y, ms, st = sm.tjds_compute(coo, m, n, iters=3, device_convert=True)
+    assert_close(y, ref, scale, exact=name in EXACT)
+    y, ms, st = sm.tjds_compute(coo, m, n, iters=1, device_convert=True, ref_quirks=True)
+    assert_close(y, ob.tjds_spmv(ob.tjds_build(coo, m, n), np.ones(n), refquirks=True), scale, exact=name in EXACT)
+
+
+def test_cli_device_convert_flag(torch, tmp_path):
+    p = subprocess.run([sm.CLI_PATH, "--all-algs", "--device-convert", "-n", "3", "-d", str(tmp_path),
+                        ob.fixture_path("curtis54.mtx")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    want = ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_1615284695.txt"))
+    for f in os.listdir(tmp_path):
+        assert ob.report_y_lines(open(tmp_path / f).read()) == want
