@@ -94,13 +94,40 @@ def timed_region(torch, dist, world, steps, body):
     return wall, ev_ms
 
 
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def golden_file(kind, name):
+    """Plain path of a committed data fixture (tests/golden/<kind>/<name>[.gz]); .gz files are inflated once into a
+    per-user temp dir.  Ranks may race here: each writes its own temp file and renames it into place."""
+    import gzip
+    import shutil
+    import tempfile
+
+    plain = os.path.join(GOLDEN, kind, name)
+    if os.path.exists(plain):
+        return plain
+    cache = os.path.join(tempfile.gettempdir(), "smvp_bench_cache_%d" % os.getuid())
+    os.makedirs(cache, exist_ok=True)
+    out = os.path.join(cache, name)
+    if not os.path.exists(out):
+        fd, tmp = tempfile.mkstemp(prefix=name + ".", dir=cache)
+        with gzip.open(plain + ".gz", "rb") as src, os.fdopen(fd, "wb") as dst:
+            shutil.copyfileobj(src, dst)
+        os.replace(tmp, out)
+    return out
+
+
+def report_y_lines(name):
+    lines = open(golden_file("reports", name)).read().split("\n")
+    return lines[lines.index("[") + 1:lines.index("]")]
+
+
 def build_block(sm, sharding, workload, args, rank, world):
     """This rank's row block of the workload -> dict with host CSR arrays and a description."""
     t0 = time.perf_counter()
     if workload == "memplus_tiled":
-        import oracle_binding as ob           # fixture lookup only (tests/golden/sample-data/memplus.mtx.gz)
-
-        tc, m, n, coo = sm.mm_read_coo(ob.fixture_path("memplus.mtx"))
+        tc, m, n, coo = sm.mm_read_coo(golden_file("sample-data", "memplus.mtx"))
         rp, ci, v = sm.csr_from_coo(coo, m)
         copies = args.copies - args.copies % world if args.copies >= world else world
         c0, c1 = copies * rank // world, copies * (rank + 1) // world
@@ -177,19 +204,26 @@ def measure_csr(torch, dist, sm, sharding_mod, blk, args, world, local_rank, ran
         raise SystemExit("rank %d: product is wrong on %s (max normwise error %g)" % (rank, blk["name"], worst))
     golden = None
     if blk["base"] is not None and args.x == "ones":
-        # full-size parity against the reference's own golden vector: y = tile(y_memplus), whose "%g" text is the
-        # committed report output-test/smvp-toolbox_report_CSR_1615284663.txt
-        import oracle_binding as ob
-
+        # full-size parity against the reference's own golden vector: y must be tile(y_memplus), and y_memplus is
+        # printed with "%g" in the committed report output-test/smvp-toolbox_report_CSR_1615284663.txt.  No oracle
+        # here: the base product runs on the GPU too and is compared with the report's text.
         m, n, rp, ci, v, ncopies = blk["base"]
-        y_base = ob.csr_spmv(rp, ci, v, np.ones(n))
-        report_ok = ob.fmt_g(y_base) == ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_1615284663.txt"))
-        sc = ob.csr_spmv(rp, ci, np.abs(v), np.ones(n))
+        B = sm.CsrMatrix(m, n, rp, ci, v, device=local_rank)
+        d_yb = torch.empty(m, dtype=torch.float64, device="cuda")
+        B.spmv(d_x[:n], d_yb, stream=stream)
+        torch.cuda.synchronize()
+        B.close()
+        y_base = d_yb.cpu().numpy()
+        want = report_y_lines("smvp-toolbox_report_CSR_1615284663.txt")
+        sc = np.add.reduceat(np.abs(v), rp[:-1])
+        short = np.diff(rp) <= 32                       # summed left to right by one lane: bit-exact => same "%g" text
+        text_ok = all(("%g" % y_base[i]) == want[i] for i in np.flatnonzero(short))
+        num_ok = bool(np.all(np.abs(y_base - np.array([float(s) for s in want])) <= 1e-5 * sc + 1e-300))
         tiles_ok = bool(np.all(np.abs(got.reshape(ncopies, m) - y_base[None, :]) <= TOL * sc[None, :]))
-        bit_identical = float((got.reshape(ncopies, m) == y_base[None, :]).mean())
-        if not (report_ok and tiles_ok):
-            raise SystemExit("rank %d: y is not tile(y_memplus)" % rank)
-        golden = {"y_equals_tiled_reference_memplus_y": True, "rows_bit_identical_to_serial": round(bit_identical, 4)}
+        if not (text_ok and num_ok and tiles_ok):
+            raise SystemExit("rank %d: y is not tile(y_memplus of the committed report)" % rank)
+        golden = {"y_equals_tiled_reference_memplus_y": True,
+                  "report_text_equal_on_rows_upto_32_entries": int(short.sum()), "rows_per_copy": int(m)}
     if gather:
         chk = float(d_y_full.sum().item())
         t = torch.tensor([chk, -chk], dtype=torch.float64, device="cuda")
@@ -356,7 +390,8 @@ def main():
                "ms_per_product": round(float(ms.mean()), 2),
                "sample": "the full workload matrix, %d products of the serial loop (oracle restatement of "
                          "main-cli.c:410-416, gcc -O3 -DNDEBUG, y reset outside the window)" % iters,
-               "agrees_with_gpu": bool(np.all(np.abs(y_cpu - res["got"]) <= TOL * res["scale"]))}
+               "agrees_with_gpu": bool(np.all(np.abs(y_cpu - res["got"]) <= TOL * res["scale"])),
+               "gpu_rows_bit_identical_to_serial": round(float((y_cpu == res["got"]).mean()), 4)}
 
     headline_roofline = roofline_of(res, blk["name"] + ", CSR, x=%s" % args.x)
     res["A"].close()

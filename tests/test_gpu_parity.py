@@ -445,6 +445,7 @@ def test_bench_script_runs_small(torch):
     assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
     assert j["cpu_baseline"]["cores"] == 1 and j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["agrees_with_gpu"]
     assert j["extra"]["full_size_parity"]["y_equals_tiled_reference_memplus_y"]
+    assert j["cpu_baseline"]["gpu_rows_bit_identical_to_serial"] > 0.98
     assert "error" not in j["extra"]["tjds"] and "error" not in j["extra"]["survey_random_model"]
 
 
