@@ -181,7 +181,9 @@ def measure_csr(torch, dist, sm, sharding_mod, blk, args, world, local_rank, ran
     x_host = np.ones(blk["cols_total"]) if args.x == "ones" else np.random.default_rng(67890).random(blk["cols_total"])
     d_x = torch.from_numpy(x_host).cuda()
     d_y_full = torch.zeros(blk["rows_total"], dtype=torch.float64, device="cuda")
-    d_y = d_y_full[blk["r0"]:blk["r1"]]
+    # one rank: the product writes the full vector; several: each rank's block has its own buffer and the
+    # all-gather assembles the full y on every GPU (no aliasing between send and receive buffers)
+    d_y = d_y_full if world == 1 else torch.zeros(blk["rows"], dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream()
     gather = collective and world > 1
 
@@ -192,7 +194,7 @@ def measure_csr(torch, dist, sm, sharding_mod, blk, args, world, local_rank, ran
 
     def step():
         A.spmv(d_x, d_y, stream=stream)
-        if gather:      # equal row blocks: gathered in place into the full y (d_y is this rank's slice of it)
+        if gather:      # equal row blocks: one all_gather_into_tensor straight into the full y
             sharding_mod.allgather_y(dist, d_y, d_y_full, bounds)
 
     # correctness gate before any timing
