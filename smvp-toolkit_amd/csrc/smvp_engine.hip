@@ -25,6 +25,25 @@
 
 namespace {
 
+// Runs the launches of one call on the handle's device, whatever the caller's current device is.
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != device)
+            switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceScope()
+    {
+        if (switched)
+            (void)hipSetDevice(prev);
+    }
+};
+
+// 32-bit indices like the reference's; the kernels add up to a few thousand to an entry index
+constexpr long long kMaxEntries = 2147483647ll - 65536;
+
 int usable_device(int device)
 {
     int n = 0;
@@ -184,6 +203,8 @@ extern "C" int smvp_csr_create(smvp_csr_t **out, int device, int rows, int cols,
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: bad argument");
     if (mem_kind != SMVP_MEM_HOST && mem_kind != SMVP_MEM_DEVICE)
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: bad mem_kind");
+    if (nnz > kMaxEntries)
+        return smvp::fail(SMVP_ERR_UNSUPPORTED, "smvp_csr_create: %d entries: shard blocks this large by rows", nnz);
     if (int rc = usable_device(device))
         return rc;
     HIP_TRY(hipSetDevice(device));
@@ -273,6 +294,9 @@ extern "C" int smvp_csr_spmv(smvp_csr_t *h, const double *d_x, double *d_y, void
 {
     if (!h || (h->rows > 0 && !d_y) || (h->nnz > 0 && !d_x))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_spmv: bad argument");
+    if (h->kernel != SMVP_CSR_KERNEL_VECTOR && !h->d_tile_row)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_spmv: the handle has no launch plan (a re-plan failed earlier)");
+    DeviceScope on(h->device);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
     if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
@@ -399,6 +423,8 @@ extern "C" int smvp_tjds_create(smvp_tjds_t **out, int device, int rows, int col
         return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_create: bad argument");
     if (mem_kind != SMVP_MEM_HOST && mem_kind != SMVP_MEM_DEVICE)
         return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_create: bad mem_kind");
+    if (nnz > kMaxEntries)
+        return smvp::fail(SMVP_ERR_UNSUPPORTED, "smvp_tjds_create: %d entries: shard blocks this large by rows", nnz);
     if (int rc = usable_device(device))
         return rc;
     HIP_TRY(hipSetDevice(device));
@@ -462,6 +488,7 @@ extern "C" int smvp_tjds_set_x(smvp_tjds_t *h, const double *d_x, void *stream)
 {
     if (!h || (h->cols > 0 && !d_x))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_set_x: bad argument");
+    DeviceScope on(h->device);
     hipError_t e = smvp::launch_tjds_permute(h->d_perm, d_x, h->d_x_perm, h->cols, (hipStream_t)stream);
     if (e != hipSuccess)
         return smvp::fail(SMVP_ERR_HIP, "operand permute launch failed: %s", hipGetErrorString(e));
@@ -473,6 +500,7 @@ extern "C" int smvp_tjds_zero_y(smvp_tjds_t *h, double *d_y, void *stream)
 {
     if (!h || (h->rows > 0 && !d_y))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_zero_y: bad argument");
+    DeviceScope on(h->device);
     if (h->rows > 0)
         HIP_TRY(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)h->rows, (hipStream_t)stream));
     return SMVP_OK;
@@ -486,6 +514,7 @@ extern "C" int smvp_tjds_spmv(smvp_tjds_t *h, double *d_y, void *stream)
         return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_spmv: call smvp_tjds_set_x first");
     if (h->quirks && h->rows != h->cols)
         return smvp::fail(SMVP_ERR_UNSUPPORTED, "ref-quirks mode indexes the operand by row and needs a square matrix");
+    DeviceScope on(h->device);
     hipError_t e = smvp::launch_tjds_scatter(h->quirks, h->d_plan_start_pos, h->d_row_ind, h->d_val, h->d_x_perm, d_y,
                                              h->d_work, h->nwork, h->cols, (hipStream_t)stream);
     if (e != hipSuccess)
