@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
             double acc = 0.0;
             for (int i = a - lo; i < z - lo; ++i)
                 acc += prod[i];
-            y[r] = acc;
+            __builtin_nontemporal_store(acc, &y[r]);
         } else {
             long_rows[atomicAdd(&long_count, 1)] = r;
         }
