@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--x", default="ones", choices=["ones", "random"])
     ap.add_argument("--no-tjds", action="store_true", help="skip the TJDS leg (extra.tjds)")
     ap.add_argument("--no-random-model", action="store_true", help="skip extra.survey_random_model")
+    ap.add_argument("--no-samples", action="store_true", help="skip extra.sample_matrices (BASELINE configs 2, 3, 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0, help="0 = sized for about 15 s")
     ap.add_argument("--no-allgather", action="store_true", help="N > 1: time the local products only")
@@ -394,6 +395,38 @@ def main():
                          "main-cli.c:410-416, gcc -O3 -DNDEBUG, y reset outside the window)" % iters,
                "agrees_with_gpu": bool(np.all(np.abs(y_cpu - res["got"]) <= TOL * res["scale"])),
                "gpu_rows_bit_identical_to_serial": round(float((y_cpu == res["got"]).mean()), 4)}
+
+    # ------------------------------------------------------------ the reference's own sample matrices, -n 1000
+    # BASELINE configs 2/3 (memplus.mtx CSR / TJDS) and 5 (pwt.mtx CSR + TJDS back to back) through the
+    # reference-shaped entry points: per-iteration hipEvent windows, y cleared outside them.  Cache-resident
+    # and launch-bound (1.9 / 2.9 MB of traffic): no HBM roofline is claimed for these.
+    if rank == 0 and world == 1 and not args.no_samples:
+        samples = {}
+        for name in ("memplus.mtx", "pwt.mtx"):
+            try:
+                tc, m, n, coo = sm.mm_read_coo(golden_file("sample-data", name))
+                y_c, ms_c, st_c = sm.csr_compute(coo, m, n, iters=1000, device=local_rank)
+                y_t, ms_t, st_t = sm.tjds_compute(coo, m, n, iters=1000, device=local_rank)
+                e = {"rows": m, "nnz": len(coo), "iters": 1000,
+                     "csr_avg_ms": round(st_c.time_avg, 6), "csr_min_ms": round(st_c.time_min, 6),
+                     "csr_GFLOPs": round(2.0 * len(coo) / st_c.time_avg * 1e-6, 2),
+                     "tjds_avg_ms": round(st_t.time_avg, 6), "tjds_min_ms": round(st_t.time_min, 6),
+                     "tjds_GFLOPs": round(2.0 * len(coo) / st_t.time_avg * 1e-6, 2)}
+                if not args.no_cpu_baseline:
+                    import oracle_binding as ob      # CPU baseline leg: the serial loops on this host, 1 thread
+
+                    rp, ci, v = ob.csr_build(coo, m)
+                    y_cpu, ms_cpu = ob.csr_timed(rp, ci, v, np.ones(n), 1000)
+                    yt_cpu, mst_cpu = ob.tjds_timed(ob.tjds_build(coo, m, n), np.ones(n), 1000)
+                    sc = ob.csr_spmv(rp, ci, np.abs(v), np.ones(n))
+                    e.update(cpu_csr_avg_ms=round(float(ms_cpu.mean()), 6), cpu_tjds_avg_ms=round(float(mst_cpu.mean()), 6),
+                             csr_agrees_with_cpu=bool(np.all(np.abs(y_c - y_cpu) <= TOL * sc)),
+                             tjds_agrees_with_cpu=bool(np.all(np.abs(y_t - yt_cpu) <= TOL * sc)),
+                             csr_rows_bit_identical=round(float((y_c == y_cpu).mean()), 4))
+                samples[name] = e
+            except Exception as ex:
+                samples[name] = {"error": str(ex)}
+        extra["sample_matrices"] = samples
 
     headline_roofline = roofline_of(res, blk["name"] + ", CSR, x=%s" % args.x)
     res["A"].close()

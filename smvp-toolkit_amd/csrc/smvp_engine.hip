@@ -69,6 +69,26 @@ int to_device(T **dst, const T *src, size_t count, int mem_kind, bool *owned)
     return SMVP_OK;
 }
 
+// Device-resident index arrays are range-checked on the device (host arrays are checked on the host).
+int check_device_indices(const int *d_a, long long n, int limit, const char *what)
+{
+    if (n <= 0)
+        return SMVP_OK;
+    int *d_bad = nullptr, h_bad = 0;
+    HIP_TRY(hipMalloc((void **)&d_bad, sizeof(int)));
+    hipError_t e = hipMemset(d_bad, 0, sizeof(int));
+    if (e == hipSuccess)
+        e = smvp::launch_find_out_of_range(d_a, n, limit, d_bad, nullptr);
+    if (e == hipSuccess)
+        e = hipMemcpy(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess)
+        return smvp::fail(SMVP_ERR_HIP, "range check of %s failed: %s", what, hipGetErrorString(e));
+    if (h_bad)
+        return smvp::fail(SMVP_ERR_INVALID, "%s[%d] lies outside [0, %d)", what, h_bad - 1, limit);
+    return SMVP_OK;
+}
+
 template <class T>
 int upload(T **dst, const std::vector<T> &src)
 {
@@ -240,6 +260,8 @@ extern "C" int smvp_csr_create(smvp_csr_t **out, int device, int rows, int cols,
     if (rc == SMVP_OK && mem_kind == SMVP_MEM_DEVICE &&
         (((uintptr_t)col_ind | (uintptr_t)val) & 15u) != 0)
         rc = smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: adopted device arrays must be 16-byte aligned");
+    if (rc == SMVP_OK && mem_kind == SMVP_MEM_DEVICE)
+        rc = check_device_indices(col_ind, nnz, cols, "smvp_csr_create: col_ind");
     if (rc == SMVP_OK)
         rc = to_device(&h->d_row_ptr, row_ptr, (size_t)rows + 1, mem_kind, &h->own_row_ptr);
     if (rc == SMVP_OK)
@@ -460,6 +482,10 @@ extern "C" int smvp_tjds_create(smvp_tjds_t **out, int device, int rows, int col
             if (perm[k] < 0 || perm[k] >= cols)
                 rc = smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_create: perm[%d] = %d outside [0, %d)", k, perm[k], cols);
     }
+    if (rc == SMVP_OK && mem_kind == SMVP_MEM_DEVICE)
+        rc = check_device_indices(row_ind, nnz, rows, "smvp_tjds_create: row_ind");
+    if (rc == SMVP_OK && mem_kind == SMVP_MEM_DEVICE)
+        rc = check_device_indices(perm, cols, cols, "smvp_tjds_create: perm");
     if (rc == SMVP_OK)
         rc = to_device(&h->d_perm, perm, (size_t)cols, mem_kind, &h->own_perm);
     if (rc == SMVP_OK)

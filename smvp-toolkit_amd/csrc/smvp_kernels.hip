@@ -412,6 +412,19 @@ __global__ __launch_bounds__(256) void tjds_permute_operand(
         x_perm[k] = x[perm[k]];
 }
 
+// first index (plus one) whose value lies outside [0, limit): adopted device arrays are checked
+// before any kernel indexes with them
+__global__ __launch_bounds__(256) void find_out_of_range(const int *__restrict__ a, long long n, int limit,
+                                                          int *__restrict__ bad)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const int v = a[i];
+        if (v < 0 || v >= limit)
+            atomicMax(bad, (int)(i < 2147483646ll ? i + 1 : 2147483647ll));
+    }
+}
+
 __global__ __launch_bounds__(256) void fill_value(double *__restrict__ p, double v, long long n)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -532,6 +545,16 @@ hipError_t launch_tjds_permute(const int *perm, const double *x, double *x_perm,
     if (cols <= 0)
         return hipSuccess;
     hipLaunchKernelGGL(tjds_permute_operand, dim3((cols + 255) / 256), dim3(256), 0, stream, perm, x, x_perm, cols);
+    return hipGetLastError();
+}
+
+hipError_t launch_find_out_of_range(const int *a, long long n, int limit, int *bad, hipStream_t stream)
+{
+    if (n <= 0)
+        return hipSuccess;
+    const long long want = (n + 255) / 256;
+    hipLaunchKernelGGL(find_out_of_range, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, stream, a, n,
+                       limit, bad);
     return hipGetLastError();
 }
 

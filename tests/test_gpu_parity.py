@@ -266,6 +266,21 @@ def test_create_rejects_malformed_arrays(torch):
         sm.TjdsMatrix(t)
 
 
+def test_adopted_device_arrays_are_range_checked(torch):
+    """A column / row index outside the matrix in an adopted device array must be refused, not dereferenced."""
+    rp = dev(torch, np.array([0, 2, 3], np.int32))
+    v = dev(torch, np.ones(4))[:3]
+    with pytest.raises(sm.SmvpError) as e:
+        sm.CsrMatrix(2, 5, rp, dev(torch, np.array([0, 9, 1, 0], np.int32))[:3], v)
+    assert e.value.code == sm.ERR_INVALID and "col_ind[1]" in str(e.value)
+    with pytest.raises(sm.SmvpError):
+        sm.CsrMatrix(2, 5, rp, dev(torch, np.array([0, -1, 1, 0], np.int32))[:3], v)
+    t = sm.tjds_from_coo_device(_coo_to_device(torch, sm.make_coo([0, 1], [0, 1], [1.0, 2.0])), 2, 2, 2)
+    t.row_ind = dev(torch, np.array([0, 7], np.int32))
+    with pytest.raises(sm.SmvpError):
+        sm.TjdsMatrix(t)
+
+
 def test_adopted_device_arrays(torch):
     """SMVP_MEM_DEVICE: arrays that already live in HBM (torch tensors) are used in place."""
     rng = np.random.default_rng(5)
