@@ -189,6 +189,24 @@ int smvp_tjds_set_ref_quirks(smvp_tjds_t *h, int enable, int ref_num_tjdiag, int
 int smvp_tjds_describe(const smvp_tjds_t *h, char *kernel_name, size_t cap, double *alg_bytes);
 void smvp_tjds_destroy(smvp_tjds_t *h);
 
+/* ------------------------------------------- several GPUs, one host process */
+/* New design (the reference is one CPU thread): the matrix is cut into `ngpus` row blocks of equal
+ * height; GPU g holds block g as its own CSR / TJDS handle plus all of x and produces its slice of y;
+ * one RCCL ncclAllGather over xGMI puts the full y on every GPU.  devices NULL = 0 .. ngpus-1.
+ * librccl is dlopen'ed on first use.  (bench.py does the same with one process per GPU.) */
+typedef struct smvp_sharded smvp_sharded_t;
+int smvp_csr_sharded_create(smvp_sharded_t **out, int ngpus, const int *devices, int rows, int cols, int nnz,
+                            const int *row_ptr, const int *col_ind, const double *val); /* host CSR arrays */
+int smvp_tjds_sharded_create(smvp_sharded_t **out, int ngpus, const int *devices, const smvp_coo_t *coo,
+                             int rows, int cols, int nnz); /* an independent TJDS per row block */
+int smvp_sharded_set_x(smvp_sharded_t *h, const double *x_host); /* NULL = ones; replicated to every GPU */
+/* local products on every GPU (+ the all-gather); asynchronous.  timed != 0 brackets it with an event pair per GPU */
+int smvp_sharded_spmv(smvp_sharded_t *h, int allgather, int timed);
+int smvp_sharded_synchronize(smvp_sharded_t *h, double *ms_of_last_timed_product); /* max over the GPUs */
+int smvp_sharded_get_y(smvp_sharded_t *h, int slot, int gathered, double *y_host);
+int smvp_sharded_info(const smvp_sharded_t *h, int *ngpus, int *rows_per_gpu);
+void smvp_sharded_destroy(smvp_sharded_t *h);
+
 /* ------------------------------------------------ reference-shaped entry points */
 typedef struct smvp_run_opts {
     int device;         /* HIP device ordinal */
@@ -196,6 +214,7 @@ typedef struct smvp_run_opts {
     int csr_param;      /* 0 = default */
     int tjds_ref_quirks;/* 1: reproduce the reference's defective TJDS output */
     int convert_on_device; /* 1: COO -> CSR / TJDS on the GPU (smvp_*_from_coo_device), 0: on the host */
+    int ngpus;          /* 0 or 1: one GPU (`device`); N > 1: row blocks on GPUs 0..N-1 + RCCL all-gather of y */
     const double *x;    /* host operand, NULL = all ones (main-cli.c:368-369) */
 } smvp_run_opts_t;
 void smvp_run_opts_default(smvp_run_opts_t *o);

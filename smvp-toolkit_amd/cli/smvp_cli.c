@@ -19,7 +19,7 @@
  *     recognised and refused: out of scope for the GPU engine.
  *   - libpopt is not used (absent from the image): getopt_long("+...") gives the
  *     same POSIX ordering rule.
- * Additive flags: --device N, --ref-quirks, --device-convert, --csr-kernel auto|vector|stream|stream-carry,
+ * Additive flags: --device N, --gpus N, --ref-quirks, --device-convert, --csr-kernel auto|vector|stream|stream-carry,
  * --quiet-arrays is implied (the reference's SMVP_CSR_DEBUG array dumps,
  * main-cli.c:374-394, are not printed).
  */
@@ -42,13 +42,13 @@
 #define RESET "\x1b[0m"
 
 enum { ALG_NONE = 0, ALG_CSR = 1 << 1, ALG_TJDS = 1 << 2, ALG_CISR = 1 << 3, ALG_ALL = 256 };
-enum { OPT_DEVICE = 1000, OPT_QUIRKS, OPT_KERNEL, OPT_USAGE, OPT_DEVCONV };
+enum { OPT_DEVICE = 1000, OPT_QUIRKS, OPT_KERNEL, OPT_USAGE, OPT_DEVCONV, OPT_GPUS };
 
 static void usage(FILE *to, const char *prog)
 {
     fprintf(to,
             "Usage: %s [-acgt?] [-a|--all-algs] [-c|--csr] [-g|--cisr-gen] [-t|--tjds]\n"
-            "        [-n|--number=1000] [-s|--slots=16] [-d|--dir=./] [--device=0]\n"
+            "        [-n|--number=1000] [-s|--slots=16] [-d|--dir=./] [--device=0] [--gpus=1]\n"
             "        [--ref-quirks] [--device-convert] [--csr-kernel=auto|vector|stream|stream-carry]\n"
             "        [-?|--help] [--usage]\n"
             "        [OPTIONS] <file>\n",
@@ -66,6 +66,7 @@ static void help(const char *prog)
     puts("  -s, --slots=16           Number of slots for CISR.");
     puts("  -d, --dir=./             Output folder for reports.");
     puts("      --device=0           HIP device ordinal.");
+    puts("      --gpus=1             Shard the matrix by row blocks over this many GPUs (RCCL all-gather of y).");
     puts("      --ref-quirks         Reproduce the reference v0.6.4 TJDS output, defects included.");
     puts("      --device-convert     Build CSR / TJDS from the loaded entries on the GPU instead of the host.");
     puts("      --csr-kernel=auto    CSR kernel family: auto, vector, stream, stream-carry.");
@@ -137,11 +138,11 @@ int main(int argc, char *argv[])
         {"dir", required_argument, NULL, 'd'},     {"help", no_argument, NULL, '?'},
         {"usage", no_argument, NULL, OPT_USAGE},   {"device", required_argument, NULL, OPT_DEVICE},
         {"ref-quirks", no_argument, NULL, OPT_QUIRKS}, {"csr-kernel", required_argument, NULL, OPT_KERNEL},
-        {"device-convert", no_argument, NULL, OPT_DEVCONV},
+        {"device-convert", no_argument, NULL, OPT_DEVCONV}, {"gpus", required_argument, NULL, OPT_GPUS},
         {NULL, 0, NULL, 0}};
     const char *prog = "smvp-toolkit-cli";
     int alg_mode = ALG_NONE, calc_iter = 1000, cisr_slots = 16, device = 0, quirks = 0;
-    int csr_kernel = SMVP_CSR_KERNEL_AUTO, device_convert = 0;
+    int csr_kernel = SMVP_CSR_KERNEL_AUTO, device_convert = 0, ngpus = 1;
     const char *report_dir = "";
 
     if (argc < 2) { /* main-cli.c:1267-1271 */
@@ -200,6 +201,11 @@ int main(int argc, char *argv[])
             break;
         case OPT_DEVCONV:
             device_convert = 1;
+            break;
+        case OPT_GPUS:
+            if (parse_int(optarg, &v) != 0 || v < 1)
+                die("Invalid number of GPUs specified.");
+            ngpus = v;
             break;
         case OPT_KERNEL:
             if (strcmp(optarg, "auto") == 0)
@@ -293,6 +299,8 @@ int main(int argc, char *argv[])
             engine_fail("Selecting the GPU", rc);
         printf(CYAN "[DATA]\tCompute device %d: " RESET "%s, %d CUs, %.0f GiB\n", device, name, cus,
                (double)mem / (1024.0 * 1024.0 * 1024.0));
+        if (ngpus > 1)
+            printf(CYAN "[DATA]\tRow blocks on %d GPUs, " RESET "RCCL all-gather of the result vector after each product\n", ngpus);
     }
 
     smvp_run_opts_t opts;
@@ -301,6 +309,7 @@ int main(int argc, char *argv[])
     opts.csr_kernel = csr_kernel;
     opts.tjds_ref_quirks = quirks;
     opts.convert_on_device = device_convert;
+    opts.ngpus = ngpus;
     smvp_time_stats_t st;
     char path[4096];
 

@@ -702,6 +702,42 @@ int finish_run(RunScratch &s, int rows, int iters, double *y, double *time_each_
 
 }  // namespace
 
+// opts.ngpus > 1: the same timed loop over row blocks on several GPUs; the window is the local products
+// plus the all-gather of y, the longest GPU counts (smvp_sharded.hip)
+static int sharded_compute(bool tjds, const smvp_coo_t *coo, int rows, int cols, int nnz, int iters,
+                           const smvp_run_opts_t *o, double *y, double *time_each_ms, smvp_time_stats_t *stats)
+{
+    smvp_sharded_t *h = nullptr;
+    int rc;
+    if (tjds) {
+        rc = smvp_tjds_sharded_create(&h, o->ngpus, nullptr, coo, rows, cols, nnz);
+    } else {
+        std::vector<int> row_ptr((size_t)rows + 1), col_ind((size_t)std::max(nnz, 1));
+        std::vector<double> val((size_t)std::max(nnz, 1));
+        rc = smvp_csr_from_coo(coo, rows, nnz, row_ptr.data(), col_ind.data(), val.data());
+        if (rc == SMVP_OK)
+            rc = smvp_csr_sharded_create(&h, o->ngpus, nullptr, rows, cols, nnz, row_ptr.data(), col_ind.data(), val.data());
+    }
+    std::vector<double> local;
+    if (!time_each_ms) {
+        local.resize((size_t)iters);
+        time_each_ms = local.data();
+    }
+    if (rc == SMVP_OK)
+        rc = smvp_sharded_set_x(h, o->x);
+    for (int i = 0; rc == SMVP_OK && i < iters; ++i) {
+        rc = smvp_sharded_spmv(h, 1, 1);
+        if (rc == SMVP_OK)
+            rc = smvp_sharded_synchronize(h, &time_each_ms[i]);
+    }
+    if (rc == SMVP_OK)
+        rc = smvp_sharded_get_y(h, 0, 1, y);
+    if (rc == SMVP_OK && stats)
+        smvp_time_stats(time_each_ms, iters, stats);
+    smvp_sharded_destroy(h);
+    return rc;
+}
+
 extern "C" int smvp_csr_compute(const smvp_coo_t *coo, int rows, int cols, int nnz, int iters,
                                 const smvp_run_opts_t *opts, double *y, double *time_each_ms,
                                 smvp_time_stats_t *stats)
@@ -711,6 +747,8 @@ extern "C" int smvp_csr_compute(const smvp_coo_t *coo, int rows, int cols, int n
     const smvp_run_opts_t *o = opts ? opts : &def;
     if (iters < 1 || rows < 0 || cols < 0 || nnz < 0 || (rows > 0 && !y))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_compute: bad argument");
+    if (o->ngpus > 1)
+        return sharded_compute(false, coo, rows, cols, nnz, iters, o, y, time_each_ms, stats);
     if (int rc = usable_device(o->device))
         return rc;
     HIP_TRY(hipSetDevice(o->device));
@@ -765,6 +803,11 @@ extern "C" int smvp_tjds_compute(const smvp_coo_t *coo, int rows, int cols, int 
     const smvp_run_opts_t *o = opts ? opts : &def;
     if (iters < 1 || rows < 0 || cols < 0 || nnz < 0 || (rows > 0 && !y))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_compute: bad argument");
+    if (o->ngpus > 1) {
+        if (o->tjds_ref_quirks)
+            return smvp::fail(SMVP_ERR_UNSUPPORTED, "ref-quirks TJDS is a whole-matrix artefact: use one GPU");
+        return sharded_compute(true, coo, rows, cols, nnz, iters, o, y, time_each_ms, stats);
+    }
     if (int rc = usable_device(o->device))
         return rc;
     HIP_TRY(hipSetDevice(o->device));

@@ -32,7 +32,8 @@ class TimeStats(C.Structure):
 
 class RunOpts(C.Structure):
     _fields_ = [("device", C.c_int), ("csr_kernel", C.c_int), ("csr_param", C.c_int),
-                ("tjds_ref_quirks", C.c_int), ("convert_on_device", C.c_int), ("x", C.c_void_p)]
+                ("tjds_ref_quirks", C.c_int), ("convert_on_device", C.c_int), ("ngpus", C.c_int),
+                ("x", C.c_void_p)]
 
 
 class SmvpError(RuntimeError):
@@ -55,6 +56,8 @@ EXPORTS = [
     "smvp_csr_describe", "smvp_csr_destroy",
     "smvp_tjds_create", "smvp_tjds_set_x", "smvp_tjds_zero_y", "smvp_tjds_spmv",
     "smvp_tjds_set_ref_quirks", "smvp_tjds_describe", "smvp_tjds_destroy",
+    "smvp_csr_sharded_create", "smvp_tjds_sharded_create", "smvp_sharded_set_x", "smvp_sharded_spmv",
+    "smvp_sharded_synchronize", "smvp_sharded_get_y", "smvp_sharded_info", "smvp_sharded_destroy",
     "smvp_run_opts_default", "smvp_csr_compute", "smvp_tjds_compute",
     "smvp_time_stats", "smvp_generate_report_text",
     "smvp_synth_row_lengths", "smvp_synth_fill", "smvp_partition_rows",
@@ -89,6 +92,15 @@ def lib():
         L.smvp_tjds_destroy.restype = None
         L.smvp_csr_from_coo.argtypes = [vp, ci, ci, vp, vp, vp]
         L.smvp_tjds_from_coo.argtypes = [vp, ci, ci, ci, vp, vp, ci, vp, vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+        L.smvp_csr_sharded_create.argtypes = [C.POINTER(vp), ci, vp, ci, ci, ci, vp, vp, vp]
+        L.smvp_tjds_sharded_create.argtypes = [C.POINTER(vp), ci, vp, vp, ci, ci, ci]
+        L.smvp_sharded_set_x.argtypes = [vp, vp]
+        L.smvp_sharded_spmv.argtypes = [vp, ci, ci]
+        L.smvp_sharded_synchronize.argtypes = [vp, C.POINTER(C.c_double)]
+        L.smvp_sharded_get_y.argtypes = [vp, ci, ci, vp]
+        L.smvp_sharded_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
+        L.smvp_sharded_destroy.argtypes = [vp]
+        L.smvp_sharded_destroy.restype = None
         L.smvp_csr_from_coo_device.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
         L.smvp_tjds_from_coo_device.argtypes = [vp, ci, ci, ci, vp, vp, ci, vp, vp, C.POINTER(ci), C.POINTER(ci),
                                                 C.POINTER(ci), vp]
@@ -380,12 +392,64 @@ class TjdsMatrix:
             pass
 
 
+class ShardedMatrix:
+    """Row blocks of one matrix on several GPUs of this process (smvp_sharded_t), RCCL all-gather of y."""
+
+    def __init__(self, fmt, ngpus, rows, cols, coo=None, csr=None, devices=None):
+        self._h = C.c_void_p()
+        devs = None if devices is None else (C.c_int * ngpus)(*devices)
+        if fmt == "csr":
+            rp, ci, v = csr
+            nnz = int(rp[rows])
+            _check(lib().smvp_csr_sharded_create(C.byref(self._h), ngpus, devs, rows, cols, nnz, _p(_arr(rp, np.int32)),
+                                                 _p(_arr(ci, np.int32)), _p(_arr(v, np.float64))),
+                   "smvp_csr_sharded_create")
+        else:
+            nnz = len(coo)
+            _check(lib().smvp_tjds_sharded_create(C.byref(self._h), ngpus, devs, _p(_arr(coo, COO_DTYPE)), rows, cols,
+                                                  nnz), "smvp_tjds_sharded_create")
+        self.rows, self.cols = rows, cols
+
+    def set_x(self, x=None):
+        keep = None if x is None else _arr(x, np.float64)
+        _check(lib().smvp_sharded_set_x(self._h, None if keep is None else _p(keep)), "smvp_sharded_set_x")
+
+    def spmv(self, allgather=True, timed=True):
+        _check(lib().smvp_sharded_spmv(self._h, int(allgather), int(timed)), "smvp_sharded_spmv")
+
+    def synchronize(self):
+        ms = C.c_double()
+        _check(lib().smvp_sharded_synchronize(self._h, C.byref(ms)), "smvp_sharded_synchronize")
+        return ms.value
+
+    def get_y(self, slot=0, gathered=True):
+        y = np.zeros(max(self.rows, 1), dtype=np.float64)
+        _check(lib().smvp_sharded_get_y(self._h, slot, int(gathered), _p(y)), "smvp_sharded_get_y")
+        return y[:self.rows]
+
+    def info(self):
+        n, b = C.c_int(), C.c_int()
+        _check(lib().smvp_sharded_info(self._h, C.byref(n), C.byref(b)), "smvp_sharded_info")
+        return n.value, b.value
+
+    def close(self):
+        if self._h:
+            lib().smvp_sharded_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ------------------------------------------------- reference-shaped entry points
-def _run_opts(device, csr_kernel, csr_param, ref_quirks, x, device_convert=False):
+def _run_opts(device, csr_kernel, csr_param, ref_quirks, x, device_convert=False, ngpus=0):
     o = RunOpts()
     lib().smvp_run_opts_default(C.byref(o))
     o.device, o.csr_kernel, o.csr_param, o.tjds_ref_quirks = device, csr_kernel, csr_param, int(ref_quirks)
-    o.convert_on_device = int(device_convert)
+    o.convert_on_device, o.ngpus = int(device_convert), int(ngpus)
     keep = None
     if x is not None:
         keep = _arr(x, np.float64)
@@ -393,27 +457,28 @@ def _run_opts(device, csr_kernel, csr_param, ref_quirks, x, device_convert=False
     return o, keep
 
 
-def csr_compute(coo, rows, cols, iters=1, device=0, kernel=CSR_KERNEL_AUTO, param=0, x=None, device_convert=False):
+def csr_compute(coo, rows, cols, iters=1, device=0, kernel=CSR_KERNEL_AUTO, param=0, x=None, device_convert=False,
+                ngpus=0):
     """smvp_csr_compute: COO in, (y, per-iteration ms, TimeStats) out."""
     nnz = len(coo)
     coo = _arr(coo, COO_DTYPE)
     y = np.zeros(max(rows, 1), dtype=np.float64)
     ms = np.zeros(iters, dtype=np.float64)
     st = TimeStats()
-    o, keep = _run_opts(device, kernel, param, False, x, device_convert)
+    o, keep = _run_opts(device, kernel, param, False, x, device_convert, ngpus)
     _check(lib().smvp_csr_compute(_p(coo), rows, cols, nnz, iters, C.byref(o), _p(y), _p(ms), C.byref(st)),
            "smvp_csr_compute")
     return y[:rows], ms, st
 
 
-def tjds_compute(coo, rows, cols, iters=1, device=0, ref_quirks=False, x=None, device_convert=False):
+def tjds_compute(coo, rows, cols, iters=1, device=0, ref_quirks=False, x=None, device_convert=False, ngpus=0):
     """smvp_tjds_compute: COO in, (y, per-iteration ms, TimeStats) out."""
     nnz = len(coo)
     coo = _arr(coo, COO_DTYPE)
     y = np.zeros(max(rows, 1), dtype=np.float64)
     ms = np.zeros(iters, dtype=np.float64)
     st = TimeStats()
-    o, keep = _run_opts(device, CSR_KERNEL_AUTO, 0, ref_quirks, x, device_convert)
+    o, keep = _run_opts(device, CSR_KERNEL_AUTO, 0, ref_quirks, x, device_convert, ngpus)
     _check(lib().smvp_tjds_compute(_p(coo), rows, cols, nnz, iters, C.byref(o), _p(y), _p(ms), C.byref(st)),
            "smvp_tjds_compute")
     return y[:rows], ms, st

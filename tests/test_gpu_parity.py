@@ -567,3 +567,55 @@ def test_cli_device_convert_flag(torch, tmp_path):
     want = ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_1615284695.txt"))
     for f in os.listdir(tmp_path):
         assert ob.report_y_lines(open(tmp_path / f).read()) == want
+
+
+# --------------------------------------------------- several GPUs from one process (RCCL)
+def _gpu_counts():
+    try:
+        import torch as _t
+        n = _t.cuda.device_count()
+    except Exception:
+        n = 1
+    return [g for g in (1, 2, 4, 8) if g <= max(n, 1)]
+
+
+@pytest.mark.parametrize("ngpus", _gpu_counts())
+@pytest.mark.parametrize("name", ["ibm32.mtx", "memplus.mtx", "pwt.mtx"])
+def test_single_process_sharded_products(torch, name, ngpus):
+    """Row blocks + ncclAllGather through the C ABI (smvp_sharded_*); on a one-GPU box this runs with one block."""
+    m, n, coo = load(name)
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    x = np.random.default_rng(8).random(n)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+    scale = row_scale(row_ptr, col_ind, val, x)
+    for fmt in ("csr", "tjds"):
+        S = sm.ShardedMatrix(fmt, ngpus, m, n, coo=coo, csr=(row_ptr, col_ind, val))
+        assert S.info()[0] == ngpus and S.info()[1] * ngpus >= m
+        S.set_x(x)
+        for _ in range(3):
+            S.spmv(allgather=True, timed=True)
+            ms = S.synchronize()
+        assert ms > 0
+        for slot in range(ngpus):                      # every GPU holds the whole gathered vector
+            assert_close(S.get_y(slot, gathered=True), ref, scale)
+        assert_close(S.get_y(0, gathered=False), ref, scale)
+        S.set_x(None)                                  # the reference's operand: ones
+        S.spmv()
+        S.synchronize()
+        assert_close(S.get_y(), ob.csr_spmv(row_ptr, col_ind, val, np.ones(n)),
+                     row_scale(row_ptr, col_ind, val, np.ones(n)), exact=name in EXACT)
+        S.close()
+
+
+def test_sharded_rejects_bad_gpu_counts(torch):
+    m, n, coo = load("ibm32.mtx")
+    csr = sm.csr_from_coo(coo, m)
+    with pytest.raises(sm.SmvpError):
+        sm.ShardedMatrix("csr", torch.cuda.device_count() + 1, m, n, csr=csr)
+    with pytest.raises(sm.SmvpError):
+        sm.ShardedMatrix("csr", 0, m, n, csr=csr)
+    if torch.cuda.device_count() >= 2:
+        y, ms, st = sm.csr_compute(coo, m, n, iters=5, ngpus=2)
+        assert ob.fmt_g(y) == ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_1615284655.txt"))
+        y, ms, st = sm.tjds_compute(coo, m, n, iters=5, ngpus=2)
+        assert ob.fmt_g(y) == ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_1615284655.txt"))
