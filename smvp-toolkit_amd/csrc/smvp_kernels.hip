@@ -206,19 +206,38 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     constexpr int TILE = kStreamBlock * VPT;
     constexpr int QCAP = (TILE + kStreamOver) / kLongRow + 1;
     __shared__ double prod[TILE + kStreamOver];
-    __shared__ int long_rows[QCAP];
+    __shared__ int long_rows[QCAP];  // rows longer than kLongRow and their LDS segments, filled in phase 2b
+    __shared__ int long_a[QCAP];
+    __shared__ int long_z[QCAP];
     __shared__ int long_count;
     __shared__ double wave_sum[kStreamBlock / 64];
 
     const int b = tile_of_block(blockIdx.x, tile_group);
     if (b >= ntiles)
         return;
+    const int t = threadIdx.x;
+    const long long s = (long long)b * TILE;
+    const long long j0 = s + (long long)t * VPT;
+
+    // ---- phase 1: stream + gather + multiply.  Straight-line code, ordered so that nothing waits on more
+    // than one dependent round trip: the tile's own col_ind / val loads go out first (they depend on nothing
+    // but the block index), then the plan words, then row_ptr for phase 2 and the overflow entries, then ALL
+    // x gathers (col_ind -> x is the one dependence that cannot be avoided).
+    const bool whole = j0 + VPT <= (long long)nnz;  // this lane's entries all exist (always, except in the last tile)
+    int c[VPT];
+    double v[VPT];
+    if (whole) {
+#pragma unroll
+        for (int k = 0; k < VPT; k += 4)
+            *reinterpret_cast<int4 *>(&c[k]) = *reinterpret_cast<const int4 *>(col_ind + j0 + k);
+#pragma unroll
+        for (int k = 0; k < VPT; k += 2)
+            *reinterpret_cast<double2 *>(&v[k]) = *reinterpret_cast<const double2 *>(val + j0 + k);
+    }
     const int rlo = tile_row[b];
     const int rhi = tile_row[b + 1];
     if (rlo == rhi)
         return;  // all of this tile continues a row owned by an earlier tile
-    const int t = threadIdx.x;
-    const long long s = (long long)b * TILE;
     const int lo = (int)s;  // nnz < 2^31
     const int e = (int)(s + TILE < (long long)nnz ? s + TILE : (long long)nnz);
     const int zend = tile_next[b];  // row_ptr[rhi]: end of the last owned row, >= e
@@ -226,23 +245,16 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     const bool giant = ext > kStreamOver;
     if (t == 0)
         long_count = 0;
-
-    // ---- phase 1: stream + gather + multiply.  Straight-line code: the tile's own loads, the first
-    // kStreamBlock entries of the overflow, then ALL gathers, so that nothing waits on more than one
-    // dependent round trip (col_ind -> x).
-    const long long j0 = s + (long long)t * VPT;
     const bool over0 = !giant && t < ext;  // this lane fetches overflow entry e + t
+    const bool full_tile = s + TILE <= (long long)nnz;
     double p[VPT];
     double po = 0.0;
-    if (j0 + VPT <= (long long)nnz) {
-        int c[VPT];
-        double v[VPT];
-#pragma unroll
-        for (int k = 0; k < VPT; k += 4)
-            *reinterpret_cast<int4 *>(&c[k]) = *reinterpret_cast<const int4 *>(col_ind + j0 + k);
-#pragma unroll
-        for (int k = 0; k < VPT; k += 2)
-            *reinterpret_cast<double2 *>(&v[k]) = *reinterpret_cast<const double2 *>(val + j0 + k);
+    int rp_a = 0, rp_b = 0;
+    if (whole) {
+        if (rlo + t < rhi) {  // this lane's first row in phase 2
+            rp_a = row_ptr[rlo + t];
+            rp_b = row_ptr[rlo + t + 1];
+        }
         int co = 0;
         double vo = 0.0;
         if (over0) {
@@ -275,37 +287,41 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
             prod[e - lo + i] = val[e + i] * x[col_ind[e + i]];
     __syncthreads();
 
-    // ---- phase 2b: one lane per owned row, long rows deferred
+    // ---- phase 2b: one lane per owned row; its bounds were fetched with the tile (no global read after
+    // the barrier for the first kStreamBlock rows); long rows are queued in LDS with their bounds
     const int last = rhi - 1;
     for (int r = rlo + t; r < rhi; r += kStreamBlock) {
         if (giant && r == last)
             continue;
-        const int a = row_ptr[r];
-        const int z = row_ptr[r + 1];
+        const bool pre = full_tile && r == rlo + t;
+        const int a = (pre ? rp_a : row_ptr[r]) - lo;
+        const int z = (pre ? rp_b : row_ptr[r + 1]) - lo;
         if (z - a <= kLongRow) {
             double acc = 0.0;
-            for (int i = a - lo; i < z - lo; ++i)
+            for (int i = a; i < z; ++i)
                 acc += prod[i];
             __builtin_nontemporal_store(acc, &y[r]);
         } else {
-            long_rows[atomicAdd(&long_count, 1)] = r;
+            const int q = atomicAdd(&long_count, 1);
+            long_rows[q] = r;
+            long_a[q] = a;
+            long_z[q] = z;
         }
     }
     __syncthreads();
 
-    // ---- phase 2c: one wavefront per long row
+    // ---- phase 2c: one wavefront per long row (measured: handing a long row to the finder's own wavefront
+    // by ballot, without this queue and barrier, was 0-2 % slower -- the long rows of a tile then share one wave)
     const int nlong = long_count;
     const int lane = t & 63;
     for (int q = t >> 6; q < nlong; q += kStreamBlock / 64) {
-        const int r = long_rows[q];
-        const int a = row_ptr[r];
-        const int z = row_ptr[r + 1];
+        const int zq = long_z[q];
         double acc = 0.0;
-        for (int i = a - lo + lane; i < z - lo; i += 64)
+        for (int i = long_a[q] + lane; i < zq; i += 64)
             acc += prod[i];
         acc = shfl_down_sum<64>(acc);
         if (lane == 0)
-            y[r] = acc;
+            y[long_rows[q]] = acc;
     }
 
     // ---- phase 2d: a last row that runs far past the tile: LDS part + the rest from global memory
@@ -315,18 +331,18 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
         for (int i = a - lo + t; i < e - lo; i += kStreamBlock)
             acc += prod[i];
         for (int j = e + t; j < zend; j += 4 * kStreamBlock) {
-            int c[4];
-            double v[4];
+            int cg[4];
+            double vg[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int jj = j + u * kStreamBlock;
                 const bool in = jj < zend;
-                c[u] = in ? col_ind[jj] : 0;
-                v[u] = in ? val[jj] : 0.0;
+                cg[u] = in ? col_ind[jj] : 0;
+                vg[u] = in ? val[jj] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                acc += (j + u * kStreamBlock < zend) ? v[u] * x[c[u]] : 0.0;
+                acc += (j + u * kStreamBlock < zend) ? vg[u] * x[cg[u]] : 0.0;
         }
         acc = shfl_down_sum<64>(acc);
         if (lane == 0)
