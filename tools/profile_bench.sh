@@ -9,7 +9,7 @@ TAG=${1:-r01}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p "$OUT"
-ARGS="--no-random-model --no-tjds --no-cpu-baseline ${BENCH_ARGS:-}"
+ARGS="--no-random-model --no-tjds --no-cpu-baseline --no-samples ${BENCH_ARGS:-}"
 python3 $R/bench.py --steps 100 --warmup 10 $ARGS > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "bench failed"; tail -5 "$OUT/bench.err"; exit 1; }
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 $R/bench.py --steps 100 --warmup 10 $ARGS > "$OUT/trace.log" 2>&1 || echo "kernel-trace pass failed"
@@ -38,5 +38,7 @@ if t["traffic_bytes_per_launch"]:
 json.dump(t, open(out + "/traffic.json", "w"), indent=1)
 print(json.dumps({k: t[k] for k in ("traffic_bytes_per_launch", "alg_bytes_per_launch", "traffic_over_algorithmic") if k in t}))
 PY
+# keep the summaries, drop the bulky per-dispatch traces (gpurun copies back at most 64 MiB)
+rm -rf "$OUT/trace" "$OUT"/pmc/*_kernel_trace.csv "$OUT"/pmc/*_counter_collection.csv "$OUT"/pmc/*_agent_info.csv
 cut -c1-150 "$OUT/kernel_stats.csv" | head -6
 cat "$OUT/bench.json" | cut -c1-700
