@@ -184,9 +184,9 @@ def measure_csr(torch, dist, sm, sharding_mod, blk, args, world, local_rank, ran
     d_y_full = torch.zeros(blk["rows_total"], dtype=torch.float64, device="cuda")
     # one rank: the product writes the full vector; several: each rank's block has its own buffer and the
     # all-gather assembles the full y on every GPU (no aliasing between send and receive buffers)
-    d_y = d_y_full if world == 1 else torch.zeros(blk["rows"], dtype=torch.float64, device="cuda")
+    d_y = d_y_full if not (world > 1 or dist.is_initialized()) else torch.zeros(blk["rows"], dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream()
-    gather = collective and world > 1
+    gather = collective and (world > 1 or dist.is_initialized())
 
     def spmv_only():
         A.spmv(d_x, d_y, stream=stream)
@@ -307,7 +307,8 @@ def main():
     backend = os.environ.get("SMVP_DIST_BACKEND", "nccl")
     local_rank %= max(1, torch.cuda.device_count()) if backend != "nccl" else max(1, local_rank + 1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = os.environ.get("SMVP_FORCE_DIST") == "1" and "RANK" in os.environ   # rehearse RCCL with one rank
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -465,7 +466,7 @@ def main():
             "roofline": headline_roofline, "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -30,7 +30,7 @@ def allgather_y(dist, y_local, y_full, bounds, wire=None, group=None):
 
     counts, pad = gather_counts(bounds)
     world = len(counts)
-    if world == 1:
+    if world == 1 and not (hasattr(dist, "is_initialized") and dist.is_initialized()):
         y_full[:counts[0]].copy_(y_local[:counts[0]])
         return y_full
     if int(counts.min()) == pad:
