@@ -182,6 +182,12 @@ int smvp_tjds_set_x(smvp_tjds_t *h, const double *d_x, void *stream);
  * smvp_tjds_zero_y does that on the same stream. */
 int smvp_tjds_zero_y(smvp_tjds_t *h, double *d_y, void *stream);
 int smvp_tjds_spmv(smvp_tjds_t *h, double *d_y, void *stream);
+/* How the scatter is carried out.  TWO_PHASE (default): products stored once per entry, then summed per row
+ * through a row-inverted index built at create time -- no atomics, bit-reproducible, y needs no zeroing
+ * (smvp_tjds_zero_y becomes a no-op).  ATOMIC: one pass, fp64 atomic adds into a zeroed y (order varies from
+ * run to run).  Ref-quirks mode always runs the atomic form. */
+enum { SMVP_TJDS_MODE_AUTO = 0, SMVP_TJDS_MODE_ATOMIC = 1, SMVP_TJDS_MODE_TWO_PHASE = 2 };
+int smvp_tjds_set_mode(smvp_tjds_t *h, int mode);
 /* Reference-defect emulation for parity with the committed TJDS reports
  * (diagonal count from original column 0, missing terminator, operand indexed
  * by row: main-cli.c:865,951-966,1018).  Host-side edit of the plan; same kernel. */

@@ -10,3 +10,9 @@ namespace smvp {
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 void clear_error();
 }  // namespace smvp
+
+// internal, device side (smvp_convert_device.hip): see its definition
+struct ihipStream_t;
+namespace smvp {
+int build_row_inverse(const int *d_row_ind, int nnz, int rows, int *d_inv_ptr, int *d_inv_pos, ihipStream_t *stream);
+}

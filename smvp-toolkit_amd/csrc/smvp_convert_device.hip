@@ -218,6 +218,59 @@ int check_device(const void *p, const char *who)
 
 }  // namespace
 
+namespace {
+
+__global__ __launch_bounds__(256) void row_keys(const int *__restrict__ row_ind, int nnz, unsigned *__restrict__ key,
+                                                unsigned *__restrict__ pos, int *__restrict__ row_count)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nnz)
+        return;
+    const int r = row_ind[j];
+    key[j] = (unsigned)r;
+    pos[j] = (unsigned)j;
+    atomicAdd(&row_count[r], 1);
+}
+
+}  // namespace
+
+namespace smvp {
+
+// Row-inverted index of a scattered product (TJDS): inv_pos[inv_ptr[r] .. inv_ptr[r+1]) lists, in ascending
+// order, the positions j with row_ind[j] == r.  One stable radix sort of (row, position) + histogram + scan.
+// row_ind must already be range-checked (it indexes the histogram).
+int build_row_inverse(const int *d_row_ind, int nnz, int rows, int *d_inv_ptr, int *d_inv_pos, hipStream_t st)
+{
+    Scratch sc;
+    unsigned *k0, *k1, *p0;
+    int *count;
+    HIP_TRY(sc.get(&k0, (size_t)nnz));
+    HIP_TRY(sc.get(&k1, (size_t)nnz));
+    HIP_TRY(sc.get(&p0, (size_t)nnz));
+    HIP_TRY(sc.get(&count, (size_t)rows + 1));
+    HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * ((size_t)rows + 1), st));
+    if (nnz > 0) {
+        hipLaunchKernelGGL(row_keys, dim3(blocks_for(nnz)), dim3(256), 0, st, d_row_ind, nnz, k0, p0, count);
+        HIP_TRY(hipGetLastError());
+        size_t tmp_bytes = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, p0, (unsigned *)d_inv_pos, (size_t)nnz, 0u,
+                                          (unsigned)bits_for(std::max(rows, 2)), st));
+        char *tmp;
+        HIP_TRY(sc.get(&tmp, tmp_bytes));
+        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, p0, (unsigned *)d_inv_pos, (size_t)nnz, 0u,
+                                          (unsigned)bits_for(std::max(rows, 2)), st));
+    }
+    size_t tmp_bytes = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, count, d_inv_ptr, 0, (size_t)rows + 1, rocprim::plus<int>(), st));
+    char *tmp;
+    HIP_TRY(sc.get(&tmp, tmp_bytes));
+    HIP_TRY(rocprim::exclusive_scan(tmp, tmp_bytes, count, d_inv_ptr, 0, (size_t)rows + 1, rocprim::plus<int>(), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return SMVP_OK;
+}
+
+}  // namespace smvp
+
 extern "C" int smvp_csr_from_coo_device(const smvp_coo_t *d_coo, int rows, int cols, int nnz,
                                         int *d_row_ptr, int *d_col_ind, double *d_val, void *stream)
 {

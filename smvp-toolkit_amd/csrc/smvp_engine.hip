@@ -112,6 +112,7 @@ struct smvp_csr {
     bool own_row_ptr = false, own_col_ind = false, own_val = false;
     std::vector<int> h_row_ptr;  // kept for re-planning
 
+    bool unit_val = false;  // every value is 1 and d_val is not read (second phase of the two-phase TJDS product)
     int kernel = SMVP_CSR_KERNEL_AUTO;  // resolved: VECTOR or STREAM
     int lanes_per_row = 64;             // VECTOR
     int vpt = 4;                        // STREAM: entries per thread (tile = 256 * vpt)
@@ -215,11 +216,11 @@ void choose_csr_kernel(smvp_csr *h, int kernel, int param)
 
 }  // namespace
 
-extern "C" int smvp_csr_create(smvp_csr_t **out, int device, int rows, int cols, int nnz,
-                               const int *row_ptr, const int *col_ind, const double *val,
-                               int mem_kind, const int *host_row_ptr)
+static int csr_create_impl(smvp_csr_t **out, int device, int rows, int cols, int nnz,
+                           const int *row_ptr, const int *col_ind, const double *val,
+                           int mem_kind, const int *host_row_ptr, bool unit_val)
 {
-    if (!out || rows < 0 || cols < 0 || nnz < 0 || !row_ptr || (nnz > 0 && (!col_ind || !val)))
+    if (!out || rows < 0 || cols < 0 || nnz < 0 || !row_ptr || (nnz > 0 && (!col_ind || (!val && !unit_val))))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: bad argument");
     if (mem_kind != SMVP_MEM_HOST && mem_kind != SMVP_MEM_DEVICE)
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: bad mem_kind");
@@ -231,6 +232,7 @@ extern "C" int smvp_csr_create(smvp_csr_t **out, int device, int rows, int cols,
 
     smvp_csr *h = new smvp_csr;
     h->device = device;
+    h->unit_val = unit_val;
     h->rows = rows, h->cols = cols, h->nnz = nnz;
     h->h_row_ptr.resize((size_t)rows + 1);
     int rc = SMVP_OK;
@@ -258,7 +260,7 @@ extern "C" int smvp_csr_create(smvp_csr_t **out, int device, int rows, int cols,
             }
     }
     if (rc == SMVP_OK && mem_kind == SMVP_MEM_DEVICE &&
-        (((uintptr_t)col_ind | (uintptr_t)val) & 15u) != 0)
+        (((uintptr_t)col_ind | (unit_val ? 0 : (uintptr_t)val)) & 15u) != 0)
         rc = smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: adopted device arrays must be 16-byte aligned");
     if (rc == SMVP_OK && mem_kind == SMVP_MEM_DEVICE)
         rc = check_device_indices(col_ind, nnz, cols, "smvp_csr_create: col_ind");
@@ -266,10 +268,11 @@ extern "C" int smvp_csr_create(smvp_csr_t **out, int device, int rows, int cols,
         rc = to_device(&h->d_row_ptr, row_ptr, (size_t)rows + 1, mem_kind, &h->own_row_ptr);
     if (rc == SMVP_OK)
         rc = to_device(&h->d_col_ind, col_ind, (size_t)nnz, mem_kind, &h->own_col_ind);
-    if (rc == SMVP_OK)
+    if (rc == SMVP_OK && !unit_val)
         rc = to_device(&h->d_val, val, (size_t)nnz, mem_kind, &h->own_val);
     if (rc == SMVP_OK) {
-        choose_csr_kernel(h, SMVP_CSR_KERNEL_AUTO, 0);
+        // the unit-value form exists for the owner-completes kernel only
+        choose_csr_kernel(h, unit_val ? SMVP_CSR_KERNEL_STREAM : SMVP_CSR_KERNEL_AUTO, 0);
         if (h->kernel != SMVP_CSR_KERNEL_VECTOR)
             rc = build_stream_plan(h);
     }
@@ -281,10 +284,19 @@ extern "C" int smvp_csr_create(smvp_csr_t **out, int device, int rows, int cols,
     return SMVP_OK;
 }
 
+extern "C" int smvp_csr_create(smvp_csr_t **out, int device, int rows, int cols, int nnz,
+                               const int *row_ptr, const int *col_ind, const double *val,
+                               int mem_kind, const int *host_row_ptr)
+{
+    return csr_create_impl(out, device, rows, cols, nnz, row_ptr, col_ind, val, mem_kind, host_row_ptr, false);
+}
+
 extern "C" int smvp_csr_set_kernel(smvp_csr_t *h, int kernel, int param)
 {
     if (!h)
         return smvp::fail(SMVP_ERR_INVALID, "null handle");
+    if (h->unit_val && kernel != SMVP_CSR_KERNEL_STREAM)
+        return smvp::fail(SMVP_ERR_UNSUPPORTED, "a unit-value matrix runs on the stream kernel only");
     if (kernel < SMVP_CSR_KERNEL_AUTO || kernel > SMVP_CSR_KERNEL_STREAM_CARRY)
         return smvp::fail(SMVP_ERR_INVALID, "unknown CSR kernel %d", kernel);
     if (kernel == SMVP_CSR_KERNEL_VECTOR && param != 0 &&
@@ -324,8 +336,8 @@ extern "C" int smvp_csr_spmv(smvp_csr_t *h, const double *d_x, double *d_y, void
     if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
         e = smvp::launch_csr_vector(h->lanes_per_row, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y, h->rows, st);
     else if (h->kernel == SMVP_CSR_KERNEL_STREAM)
-        e = smvp::launch_csr_stream_owner(h->vpt, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y, h->d_tile_row,
-                                          h->d_tile_next, h->rows, h->nnz, h->ntiles, st);
+        e = smvp::launch_csr_stream_owner(h->vpt, h->unit_val, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y,
+                                          h->d_tile_row, h->d_tile_next, h->rows, h->nnz, h->ntiles, st);
     else
         e = smvp::launch_csr_stream(h->vpt, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y, h->d_tile_row,
                                     h->d_carry_row, h->d_carry, h->rows, h->nnz, h->ntiles, st);
@@ -342,7 +354,7 @@ extern "C" int smvp_csr_describe(const smvp_csr_t *h, char *kernel_name, size_t 
         if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
             snprintf(kernel_name, cap, "csr_vector_rows<%d>", h->lanes_per_row);
         else if (h->kernel == SMVP_CSR_KERNEL_STREAM)
-            snprintf(kernel_name, cap, "csr_stream_owner<%d>", h->vpt);
+            snprintf(kernel_name, cap, h->unit_val ? "csr_stream_owner<%d, true>" : "csr_stream_owner<%d>", h->vpt);
         else
             snprintf(kernel_name, cap, "csr_stream_tiles<%d>", h->vpt);
     }
@@ -381,6 +393,13 @@ struct smvp_tjds {
 
     double *d_x_perm = nullptr;  // max(rows, cols) doubles
     bool x_set = false;
+
+    // two-phase (atomic-free) product: per-entry products + their sum per row through the row-inverted index
+    int mode = SMVP_TJDS_MODE_TWO_PHASE;
+    double *d_prod = nullptr;    // nnz doubles
+    int *d_inv_ptr = nullptr;    // rows + 1
+    int *d_inv_pos = nullptr;    // nnz: positions j grouped by row_ind[j], ascending inside a row
+    smvp_csr *inv = nullptr;     // unit-value CSR over (inv_ptr, inv_pos), x = prod
 
     // launch plan (rebuilt when ref-quirks mode changes)
     bool quirks = false;
@@ -502,11 +521,31 @@ extern "C" int smvp_tjds_create(smvp_tjds_t **out, int device, int rows, int col
     }
     if (rc == SMVP_OK)
         rc = build_tjds_plan(h, false, 0, 0);
+    if (rc == SMVP_OK) {
+        const size_t n = (size_t)std::max(nnz, 1);
+        if (hipMalloc((void **)&h->d_prod, n * sizeof(double)) != hipSuccess ||
+            hipMalloc((void **)&h->d_inv_pos, n * sizeof(int)) != hipSuccess ||
+            hipMalloc((void **)&h->d_inv_ptr, ((size_t)rows + 1) * sizeof(int)) != hipSuccess)
+            rc = smvp::fail(SMVP_ERR_ALLOC, "smvp_tjds_create: cannot allocate the two-phase buffers");
+    }
+    if (rc == SMVP_OK)
+        rc = smvp::build_row_inverse(h->d_row_ind, nnz, rows, h->d_inv_ptr, h->d_inv_pos, nullptr);
+    if (rc == SMVP_OK)
+        rc = csr_create_impl(&h->inv, device, rows, std::max(nnz, 1), nnz, h->d_inv_ptr, h->d_inv_pos, nullptr,
+                             SMVP_MEM_DEVICE, nullptr, true);
     if (rc != SMVP_OK) {
         smvp_tjds_destroy(h);
         return rc;
     }
     *out = h;
+    return SMVP_OK;
+}
+
+extern "C" int smvp_tjds_set_mode(smvp_tjds_t *h, int mode)
+{
+    if (!h || mode < SMVP_TJDS_MODE_AUTO || mode > SMVP_TJDS_MODE_TWO_PHASE)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_set_mode: bad argument");
+    h->mode = mode == SMVP_TJDS_MODE_AUTO ? SMVP_TJDS_MODE_TWO_PHASE : mode;
     return SMVP_OK;
 }
 
@@ -526,6 +565,8 @@ extern "C" int smvp_tjds_zero_y(smvp_tjds_t *h, double *d_y, void *stream)
 {
     if (!h || (h->rows > 0 && !d_y))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_zero_y: bad argument");
+    if (h->mode == SMVP_TJDS_MODE_TWO_PHASE && !h->quirks)
+        return SMVP_OK;  // the two-phase product overwrites y
     DeviceScope on(h->device);
     if (h->rows > 0)
         HIP_TRY(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)h->rows, (hipStream_t)stream));
@@ -541,6 +582,13 @@ extern "C" int smvp_tjds_spmv(smvp_tjds_t *h, double *d_y, void *stream)
     if (h->quirks && h->rows != h->cols)
         return smvp::fail(SMVP_ERR_UNSUPPORTED, "ref-quirks mode indexes the operand by row and needs a square matrix");
     DeviceScope on(h->device);
+    if (h->mode == SMVP_TJDS_MODE_TWO_PHASE && !h->quirks) {
+        hipError_t e1 = smvp::launch_tjds_products(h->d_plan_start_pos, h->d_val, h->d_x_perm, h->d_prod, h->d_work,
+                                                   h->nwork, h->cols, (hipStream_t)stream);
+        if (e1 != hipSuccess)
+            return smvp::fail(SMVP_ERR_HIP, "TJDS products launch failed: %s", hipGetErrorString(e1));
+        return smvp_csr_spmv(h->inv, h->d_prod, d_y, stream);
+    }
     hipError_t e = smvp::launch_tjds_scatter(h->quirks, h->d_plan_start_pos, h->d_row_ind, h->d_val, h->d_x_perm, d_y,
                                              h->d_work, h->nwork, h->cols, (hipStream_t)stream);
     if (e != hipSuccess)
@@ -560,8 +608,12 @@ extern "C" int smvp_tjds_describe(const smvp_tjds_t *h, char *kernel_name, size_
 {
     if (!h)
         return smvp::fail(SMVP_ERR_INVALID, "null handle");
-    if (kernel_name && cap)
-        snprintf(kernel_name, cap, "tjds_colmajor_scatter<%s>", h->quirks ? "true" : "false");
+    if (kernel_name && cap) {
+        if (h->mode == SMVP_TJDS_MODE_TWO_PHASE && !h->quirks)
+            snprintf(kernel_name, cap, "tjds_colmajor_products + csr_stream_owner<4, true>");
+        else
+            snprintf(kernel_name, cap, "tjds_colmajor_scatter<%s>", h->quirks ? "true" : "false");
+    }
     if (alg_bytes)
         *alg_bytes = 12.0 * h->planned_nnz + 4.0 * (h->num_diag + 1.0) + 8.0 * h->cols + 8.0 * h->rows;
     return SMVP_OK;
@@ -586,6 +638,10 @@ extern "C" void smvp_tjds_destroy(smvp_tjds_t *h)
         (void)hipFree(h->d_plan_start_pos);
     if (h->d_work)
         (void)hipFree(h->d_work);
+    smvp_csr_destroy(h->inv);
+    for (void *p : {(void *)h->d_prod, (void *)h->d_inv_ptr, (void *)h->d_inv_pos})
+        if (p)
+            (void)hipFree(p);
     delete h;
 }
 

@@ -17,9 +17,11 @@ hipError_t launch_csr_vector(int lanes_per_row, const int *row_ptr, const int *c
 hipError_t launch_csr_stream(int vpt, const int *row_ptr, const int *col_ind, const double *val,
                              const double *x, double *y, const int *tile_row, const int *carry_row,
                              double *carry, int rows, int nnz, int ntiles, hipStream_t stream);
-hipError_t launch_csr_stream_owner(int vpt, const int *row_ptr, const int *col_ind, const double *val,
-                                   const double *x, double *y, const int *tile_row, const int *tile_next,
-                                   int rows, int nnz, int ntiles, hipStream_t stream);
+hipError_t launch_csr_stream_owner(int vpt, bool unit_values, const int *row_ptr, const int *col_ind,
+                                   const double *val, const double *x, double *y, const int *tile_row,
+                                   const int *tile_next, int rows, int nnz, int ntiles, hipStream_t stream);
+hipError_t launch_tjds_products(const int *start_pos, const double *val, const double *x_perm, double *prod,
+                                const int4 *work, int nwork, int cols, hipStream_t stream);
 hipError_t launch_tjds_scatter(bool operand_by_row, const int *start_pos, const int *row_ind, const double *val,
                                const double *x_perm, double *y, const int4 *work, int nwork, int cols,
                                hipStream_t stream);

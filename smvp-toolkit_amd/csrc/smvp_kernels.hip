@@ -196,8 +196,12 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_tiles(
 // by the whole workgroup straight from global memory; matrices with rows far
 // longer than that are planned onto the carry kernel above instead, which
 // spreads such a row over many workgroups.
+// UNIT = true is the same kernel with every matrix value taken as 1 (val is not
+// read): y[r] = sum of x[col_ind[j]] over the row.  The TJDS path uses it as its
+// second phase, with x = the per-entry products and col_ind = the row-inverted
+// index (see tjds_colmajor_products).
 // ---------------------------------------------------------------------------
-template <int VPT>
+template <int VPT, bool UNIT>
 __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     const int *__restrict__ row_ptr, const int *__restrict__ col_ind, const double *__restrict__ val,
     const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ tile_row,
@@ -230,9 +234,11 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
 #pragma unroll
         for (int k = 0; k < VPT; k += 4)
             *reinterpret_cast<int4 *>(&c[k]) = *reinterpret_cast<const int4 *>(col_ind + j0 + k);
+        if (!UNIT) {
 #pragma unroll
-        for (int k = 0; k < VPT; k += 2)
-            *reinterpret_cast<double2 *>(&v[k]) = *reinterpret_cast<const double2 *>(val + j0 + k);
+            for (int k = 0; k < VPT; k += 2)
+                *reinterpret_cast<double2 *>(&v[k]) = *reinterpret_cast<const double2 *>(val + j0 + k);
+        }
     }
     const int rlo = tile_row[b];
     const int rhi = tile_row[b + 1];
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
         double vo = 0.0;
         if (over0) {
             co = col_ind[e + t];
-            vo = val[e + t];
+            vo = UNIT ? 1.0 : val[e + t];
         }
         double xk[VPT];
 #pragma unroll
@@ -268,14 +274,14 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
         const double xo = over0 ? x[co] : 0.0;
 #pragma unroll
         for (int k = 0; k < VPT; ++k)
-            p[k] = v[k] * xk[k];
-        po = vo * xo;
+            p[k] = UNIT ? xk[k] : v[k] * xk[k];
+        po = UNIT ? xo : vo * xo;
     } else {
 #pragma unroll
         for (int k = 0; k < VPT; ++k)
-            p[k] = (j0 + k < (long long)nnz) ? val[j0 + k] * x[col_ind[j0 + k]] : 0.0;
+            p[k] = (j0 + k < (long long)nnz) ? (UNIT ? 1.0 : val[j0 + k]) * x[col_ind[j0 + k]] : 0.0;
         if (over0)
-            po = val[e + t] * x[col_ind[e + t]];
+            po = (UNIT ? 1.0 : val[e + t]) * x[col_ind[e + t]];
     }
 #pragma unroll
     for (int k = 0; k < VPT; k += 2)
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
         prod[e - lo + t] = po;
     if (!giant)  // rare: the last row runs more than one block width past the tile
         for (int i = t + kStreamBlock; i < ext; i += kStreamBlock)
-            prod[e - lo + i] = val[e + i] * x[col_ind[e + i]];
+            prod[e - lo + i] = (UNIT ? 1.0 : val[e + i]) * x[col_ind[e + i]];
     __syncthreads();
 
     // ---- phase 2b: one lane per owned row; its bounds were fetched with the tile (no global read after
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
                 const int jj = j + u * kStreamBlock;
                 const bool in = jj < zend;
                 cg[u] = in ? col_ind[jj] : 0;
-                vg[u] = in ? val[jj] : 0.0;
+                vg[u] = in ? (UNIT ? 1.0 : val[jj]) : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -418,6 +424,40 @@ __global__ __launch_bounds__(kTjdsBlock) void tjds_colmajor_scatter(
             unsafeAtomicAdd(&y[r[i]], v[i] * xv);
         }
     }
+}
+
+// K3': the atomic-free TJDS product, phase 1.  Same traversal as tjds_colmajor_scatter -- thread k of a
+// work item is permuted column k0 + k, holds x_perm[k] in a register and walks down its column -- but the
+// product of entry j is stored to prod[j] (plain, coalesced store; row_ind is not even read).  Phase 2 sums
+// each row's products through the row-inverted index built at create time (csr_stream_owner<4, true>):
+// "store every contribution once, then sum per destination", fixed order, so the result is bit-reproducible
+// and y needs no zeroing.
+__global__ __launch_bounds__(kTjdsBlock) void tjds_colmajor_products(
+    const int *__restrict__ start_pos, const double *__restrict__ val, const double *__restrict__ x_perm,
+    double *__restrict__ prod, const int4 *__restrict__ work, int cols)
+{
+    const int4 w = work[blockIdx.x];
+    const int k = w.x + threadIdx.x;
+    const double xk = k < cols ? x_perm[k] : 0.0;
+    int j[kTjdsDiagChunk];
+    double v[kTjdsDiagChunk];
+#pragma unroll
+    for (int i = 0; i < kTjdsDiagChunk; ++i) {
+        const int d = w.y + i;
+        j[i] = -1;
+        v[i] = 0.0;
+        if (d < w.z) {
+            const int base = start_pos[d];
+            if (k < start_pos[d + 1] - base) {
+                j[i] = base + k;
+                v[i] = val[base + k];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kTjdsDiagChunk; ++i)
+        if (j[i] >= 0)
+            __builtin_nontemporal_store(v[i] * xk, &prod[j[i]]);
 }
 
 __global__ __launch_bounds__(256) void tjds_permute_operand(
@@ -518,26 +558,38 @@ hipError_t launch_csr_stream(int vpt, const int *row_ptr, const int *col_ind, co
     return e;
 }
 
-hipError_t launch_csr_stream_owner(int vpt, const int *row_ptr, const int *col_ind, const double *val,
-                                   const double *x, double *y, const int *tile_row, const int *tile_next,
-                                   int rows, int nnz, int ntiles, hipStream_t stream)
+hipError_t launch_csr_stream_owner(int vpt, bool unit_values, const int *row_ptr, const int *col_ind,
+                                   const double *val, const double *x, double *y, const int *tile_row,
+                                   const int *tile_next, int rows, int nnz, int ntiles, hipStream_t stream)
 {
     if (rows <= 0)
         return hipSuccess;
     const int group = tile_group();
     const dim3 grid((unsigned)((ntiles + 8 * group - 1) / (8 * group)) * 8u * group);
-    switch (vpt) {
-    case 4:
-        hipLaunchKernelGGL(csr_stream_owner<4>, grid, dim3(kStreamBlock), 0, stream, row_ptr, col_ind, val, x, y,
-                           tile_row, tile_next, rows, nnz, ntiles, group);
-        break;
-    case 8:
-        hipLaunchKernelGGL(csr_stream_owner<8>, grid, dim3(kStreamBlock), 0, stream, row_ptr, col_ind, val, x, y,
-                           tile_row, tile_next, rows, nnz, ntiles, group);
-        break;
-    default:
+#define SMVP_OWNER(V, U)                                                                                          \
+    hipLaunchKernelGGL((csr_stream_owner<V, U>), grid, dim3(kStreamBlock), 0, stream, row_ptr, col_ind, val, x, y, \
+                       tile_row, tile_next, rows, nnz, ntiles, group)
+    if (vpt == 4 && !unit_values)
+        SMVP_OWNER(4, false);
+    else if (vpt == 8 && !unit_values)
+        SMVP_OWNER(8, false);
+    else if (vpt == 4 && unit_values)
+        SMVP_OWNER(4, true);
+    else if (vpt == 8 && unit_values)
+        SMVP_OWNER(8, true);
+    else
         return hipErrorInvalidValue;
-    }
+#undef SMVP_OWNER
+    return hipGetLastError();
+}
+
+hipError_t launch_tjds_products(const int *start_pos, const double *val, const double *x_perm, double *prod,
+                                const int4 *work, int nwork, int cols, hipStream_t stream)
+{
+    if (nwork <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(tjds_colmajor_products, dim3(nwork), dim3(kTjdsBlock), 0, stream, start_pos, val, x_perm, prod,
+                       work, cols);
     return hipGetLastError();
 }
 

@@ -22,6 +22,7 @@ MM_COULD_NOT_READ_FILE, MM_PREMATURE_EOF, MM_NOT_MTX, MM_NO_HEADER, MM_UNSUPPORT
 CSR_KERNEL_AUTO, CSR_KERNEL_VECTOR, CSR_KERNEL_STREAM, CSR_KERNEL_STREAM_CARRY = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 SYNTH_MEMPLUS_SHAPED, SYNTH_UNIFORM = 1, 2
+TJDS_MODE_AUTO, TJDS_MODE_ATOMIC, TJDS_MODE_TWO_PHASE = 0, 1, 2
 
 COO_DTYPE = np.dtype([("row", "<i4"), ("col", "<i4"), ("val", "<f8")], align=True)
 
@@ -55,7 +56,7 @@ EXPORTS = [
     "smvp_csr_create", "smvp_csr_set_kernel", "smvp_csr_get_kernel", "smvp_csr_spmv",
     "smvp_csr_describe", "smvp_csr_destroy",
     "smvp_tjds_create", "smvp_tjds_set_x", "smvp_tjds_zero_y", "smvp_tjds_spmv",
-    "smvp_tjds_set_ref_quirks", "smvp_tjds_describe", "smvp_tjds_destroy",
+    "smvp_tjds_set_ref_quirks", "smvp_tjds_set_mode", "smvp_tjds_describe", "smvp_tjds_destroy",
     "smvp_csr_sharded_create", "smvp_tjds_sharded_create", "smvp_sharded_set_x", "smvp_sharded_spmv",
     "smvp_sharded_synchronize", "smvp_sharded_get_y", "smvp_sharded_info", "smvp_sharded_destroy",
     "smvp_run_opts_default", "smvp_csr_compute", "smvp_tjds_compute",
@@ -87,6 +88,7 @@ def lib():
         L.smvp_tjds_zero_y.argtypes = [vp, vp, vp]
         L.smvp_tjds_spmv.argtypes = [vp, vp, vp]
         L.smvp_tjds_set_ref_quirks.argtypes = [vp, ci, ci, ci]
+        L.smvp_tjds_set_mode.argtypes = [vp, ci]
         L.smvp_tjds_describe.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double)]
         L.smvp_tjds_destroy.argtypes = [vp]
         L.smvp_tjds_destroy.restype = None
@@ -369,6 +371,9 @@ class TjdsMatrix:
 
     def spmv(self, y, stream=None):
         _check(lib().smvp_tjds_spmv(self._h, _dev_ptr(y), _stream_ptr(stream)), "smvp_tjds_spmv")
+
+    def set_mode(self, mode):
+        _check(lib().smvp_tjds_set_mode(self._h, mode), "smvp_tjds_set_mode")
 
     def set_ref_quirks(self, enable=True):
         _check(lib().smvp_tjds_set_ref_quirks(self._h, int(enable), self._t.ref_num_tjdiag,

@@ -140,11 +140,14 @@ def test_auto_plan_choice(torch):
 
 
 @pytest.mark.parametrize("name", SAMPLES)
-def test_tjds_sample_matrices(torch, name):
+@pytest.mark.parametrize("mode", [sm.TJDS_MODE_TWO_PHASE, sm.TJDS_MODE_ATOMIC])
+def test_tjds_sample_matrices(torch, name, mode):
     m, n, coo = load(name)
     t = sm.tjds_from_coo(coo, m, n)
     row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
     T = sm.TjdsMatrix(t)
+    T.set_mode(mode)
+    assert ("products" in T.describe()[0]) == (mode == sm.TJDS_MODE_TWO_PHASE)
     for x in (np.ones(n), np.random.default_rng(67890).random(n)):
         ref = ob.csr_spmv(row_ptr, col_ind, val, x)          # a correct TJDS computes A x
         dy = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
@@ -235,6 +238,48 @@ def test_csr_edge_cases(torch, case, kernel, param):
     ref = ob.csr_spmv(row_ptr, col_ind, val, x)
     y = gpu_csr(torch, rows, cols, row_ptr, col_ind, val, x, kernel, param)
     assert_close(y, ref, row_scale(row_ptr, col_ind, val, x))
+
+
+def test_tjds_two_phase_is_bit_reproducible_and_needs_no_zeroing(torch):
+    """Products stored once, summed per row in a fixed order: identical bits run to run, y may hold garbage."""
+    m, n, coo = load("memplus.mtx")
+    T = sm.TjdsMatrix(sm.tjds_from_coo(coo, m, n))
+    T.set_x(dev(torch, np.random.default_rng(2).random(n)))
+    ys = []
+    for fill in (float("nan"), 7.0, -1e300):
+        dy = torch.full((m,), fill, dtype=torch.float64, device="cuda")
+        T.zero_y(dy)          # a no-op in this mode
+        T.spmv(dy)
+        torch.cuda.synchronize()
+        ys.append(dy.clone())
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    # the same through device-built arrays
+    d_coo = torch.from_numpy(np.ascontiguousarray(coo).view(np.uint8).copy()).cuda()
+    T2 = sm.TjdsMatrix(sm.tjds_from_coo_device(d_coo, m, n, len(coo)))
+    T2.set_x(dev(torch, np.random.default_rng(2).random(n)))
+    dy = torch.empty(m, dtype=torch.float64, device="cuda")
+    T2.spmv(dy)
+    torch.cuda.synchronize()
+    assert torch.equal(dy, ys[0])
+
+
+@pytest.mark.parametrize("mode", [sm.TJDS_MODE_TWO_PHASE, sm.TJDS_MODE_ATOMIC])
+@pytest.mark.parametrize("case", sorted(EDGE_CASES))
+def test_tjds_edge_cases_handles(torch, case, mode):
+    rng = np.random.default_rng(zlib.crc32(case.encode()))
+    lens, cols = EDGE_CASES[case](rng)
+    row_ptr, col_ind, val = csr_from_lengths(rng, lens, cols)
+    rows = len(lens)
+    coo = sm.make_coo(np.repeat(np.arange(rows), lens), col_ind, val)
+    x = rng.random(cols)
+    T = sm.TjdsMatrix(sm.tjds_from_coo(coo, rows, cols))
+    T.set_mode(mode)
+    T.set_x(dev(torch, x))
+    dy = torch.full((max(rows, 1),), float("nan"), dtype=torch.float64, device="cuda")
+    T.zero_y(dy)
+    T.spmv(dy)
+    torch.cuda.synchronize()
+    assert_close(dy.cpu().numpy()[:rows], ob.csr_spmv(row_ptr, col_ind, val, x), row_scale(row_ptr, col_ind, val, x))
 
 
 @pytest.mark.parametrize("case", sorted(EDGE_CASES))
