@@ -12,7 +12,9 @@
 #include <cerrno>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -169,21 +171,11 @@ extern "C" int smvp_mm_read_mtx_crd_size(FILE *f, int *rows, int *cols, int *nnz
     return SMVP_OK;
 }
 
-extern "C" int smvp_mm_read_coo_entries(FILE *f, const smvp_mm_typecode matcode, int nnz, smvp_coo_t *out)
+namespace {
+
+// The serial tokeniser: fscanf semantics (a number ends where it stops parsing, not at the next blank).
+int parse_entries_serial(const char *p, const char *end, bool pattern, int nnz, smvp_coo_t *out)
 {
-    if (!f || !matcode || nnz < 0 || (nnz > 0 && !out))
-        return smvp::fail(SMVP_ERR_INVALID, "smvp_mm_read_coo_entries: bad argument");
-    // Everything after the size line, in one buffer.
-    std::vector<char> buf;
-    {
-        char chunk[1 << 16];
-        size_t got;
-        while ((got = fread(chunk, 1, sizeof chunk, f)) > 0)
-            buf.insert(buf.end(), chunk, chunk + got);
-        buf.push_back('\0');
-    }
-    const char *p = buf.data(), *end = buf.data() + buf.size() - 1;
-    const bool pattern = (matcode[2] == 'P');
     for (int i = 0; i < nnz; ++i) {
         int r, c;
         double v = 1.0;  // main-cli.c:1432
@@ -194,6 +186,123 @@ extern "C" int smvp_mm_read_coo_entries(FILE *f, const smvp_mm_typecode matcode,
         out[i].val = v;
     }
     return SMVP_OK;
+}
+
+inline bool blank(char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+
+// Parallel tokeniser for large files.  The text is cut into one chunk per thread at
+// blanks; pass 1 counts each chunk's tokens, a prefix sum gives every chunk its first global token number,
+// pass 2 parses token g into entry g / per_entry, field g % per_entry.  A token that is not one complete
+// number makes the caller fall back to the serial tokeniser, which reproduces fscanf on such input.
+bool parse_entries_parallel(const char *begin, const char *end, bool pattern, int nnz, smvp_coo_t *out, int threads)
+{
+    const int per_entry = pattern ? 2 : 3;
+    const long long want = (long long)nnz * per_entry;
+    std::vector<const char *> cut((size_t)threads + 1);
+    cut[0] = begin;
+    cut[(size_t)threads] = end;
+    for (int t = 1; t < threads; ++t) {
+        const char *q = begin + (end - begin) * t / threads;
+        while (q < end && !blank(*q))
+            ++q;  // never split a token
+        cut[(size_t)t] = q;
+    }
+    std::vector<long long> count((size_t)threads, 0), first((size_t)threads + 1, 0);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&, t] {
+            long long n = 0;
+            bool in = false;
+            for (const char *q = cut[(size_t)t]; q < cut[(size_t)t + 1]; ++q) {
+                const bool b = blank(*q);
+                n += (!b && !in);
+                in = !b;
+            }
+            count[(size_t)t] = n;
+        });
+    for (auto &th : pool)
+        th.join();
+    pool.clear();
+    for (int t = 0; t < threads; ++t)
+        first[(size_t)t + 1] = first[(size_t)t] + count[(size_t)t];
+    if (first[(size_t)threads] < want)
+        return false;  // short file: let the serial pass produce the error with its entry number
+
+    std::vector<char> ok((size_t)threads, 1);
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&, t] {
+            long long g = first[(size_t)t];
+            const char *q = cut[(size_t)t], *stop = cut[(size_t)t + 1];
+            while (g < want) {
+                while (q < stop && blank(*q))
+                    ++q;
+                if (q >= stop)
+                    break;
+                const long long entry = g / per_entry;
+                const int field = (int)(g % per_entry);
+                char *after = nullptr;
+                if (field < 2) {
+                    const long v = strtol(q, &after, 10);
+                    (field == 0 ? out[entry].row : out[entry].col) = (int)v - 1;
+                    if (pattern && field == 1)
+                        out[entry].val = 1.0;
+                } else {
+                    out[entry].val = strtod(q, &after);
+                }
+                if (after == q || (after < end && !blank(*after))) {
+                    ok[(size_t)t] = 0;  // e.g. "1.5" in an index column: not this tokeniser's business
+                    return;
+                }
+                q = after;
+                ++g;
+            }
+        });
+    for (auto &th : pool)
+        th.join();
+    for (char o : ok)
+        if (!o)
+            return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int smvp_mm_read_coo_entries(FILE *f, const smvp_mm_typecode matcode, int nnz, smvp_coo_t *out)
+{
+    if (!f || !matcode || nnz < 0 || (nnz > 0 && !out))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_mm_read_coo_entries: bad argument");
+    // Everything after the size line, in one buffer.
+    std::vector<char> buf;
+    {
+        const long here = ftell(f);
+        long size = -1;
+        if (here >= 0 && fseek(f, 0, SEEK_END) == 0) {
+            size = ftell(f);
+            fseek(f, here, SEEK_SET);
+        }
+        if (size > here) {
+            buf.resize((size_t)(size - here) + 1);
+            const size_t got = fread(buf.data(), 1, (size_t)(size - here), f);
+            buf.resize(got + 1);
+        } else {  // not seekable: read in pieces
+            char chunk[1 << 16];
+            size_t got;
+            while ((got = fread(chunk, 1, sizeof chunk, f)) > 0)
+                buf.insert(buf.end(), chunk, chunk + got);
+            buf.push_back('\0');
+        }
+        buf.back() = '\0';
+    }
+    const char *p = buf.data(), *end = buf.data() + buf.size() - 1;
+    const bool pattern = (matcode[2] == 'P');
+    // SMVP_MM_THREADS overrides the thread count (1 = always serial); small files are not worth the threads
+    int threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("SMVP_MM_THREADS"))
+        threads = std::max(1, atoi(e));
+    const bool big = (end - p) >= (8 << 20) || getenv("SMVP_MM_THREADS");
+    if (threads > 1 && big && nnz > 0 && parse_entries_parallel(p, end, pattern, nnz, out, threads))
+        return SMVP_OK;
+    return parse_entries_serial(p, end, pattern, nnz, out);
 }
 
 extern "C" int smvp_mm_read_header_path(const char *path, smvp_mm_typecode *matcode, int *rows, int *cols, int *nnz)

@@ -284,3 +284,48 @@ def test_partition_rows_balances_bytes():
         assert b[0] == 0 and b[-1] == m and np.all(np.diff(b) >= 0)
         cost = 12.0 * np.diff(row_ptr[b]) + 20.0 * np.diff(b)
         assert cost.max() <= cost.sum() / parts + 12.0 * 574 + 20.0
+
+
+# ------------------------------------------------- parallel Matrix Market tokeniser
+def _write_mtx(path, rows, cols, r, c, v, pattern=False, sep="\n"):
+    with open(path, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate %s general\n%% generated\n%d %d %d\n" %
+                ("pattern" if pattern else "real", rows, cols, len(r)))
+        if pattern:
+            f.write(sep.join("%d %d" % (a + 1, b + 1) for a, b in zip(r, c)))
+        else:
+            f.write(sep.join("%d %d %.17g" % (a + 1, b + 1, x) for a, b, x in zip(r, c, v)))
+        f.write("\n")
+
+
+@pytest.mark.parametrize("threads", ["1", "2", "7", "16"])
+@pytest.mark.parametrize("pattern", [False, True])
+def test_parallel_tokeniser_equals_serial(tmp_path, monkeypatch, threads, pattern):
+    rng = np.random.default_rng(42)
+    n = 20000
+    r, c = rng.integers(0, 5000, n), rng.integers(0, 7000, n)
+    v = rng.uniform(-1e3, 1e3, n) * 10.0 ** rng.integers(-20, 20, n)
+    p = str(tmp_path / "m.mtx")
+    _write_mtx(p, 5000, 7000, r, c, v, pattern=pattern, sep="\n" if not pattern else "  \t\n ")
+    monkeypatch.setenv("SMVP_MM_THREADS", threads)
+    tc, m, k, coo = sm.mm_read_coo(p)
+    assert (m, k, len(coo)) == (5000, 7000, n)
+    assert np.array_equal(coo["row"], r) and np.array_equal(coo["col"], c)
+    assert np.array_equal(coo["val"], np.ones(n) if pattern else v)
+
+
+def test_parallel_tokeniser_on_sample_and_fallbacks(tmp_path, monkeypatch):
+    monkeypatch.setenv("SMVP_MM_THREADS", "8")
+    tc, m, n, coo = sm.mm_read_coo(ob.fixture_path("memplus.mtx"))
+    rc, tc2, m2, n2, coo2 = ob.mm_read_coo(ob.fixture_path("memplus.mtx"))
+    assert coo.tobytes() == coo2.tobytes()
+    # a token the strict tokeniser refuses ("2.5" where an index belongs) goes through the fscanf-like serial path
+    p = tmp_path / "odd.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real general\n3 3 2\n1 1 4.0\n2 2.5 7\n")
+    tc, m, n, coo = sm.mm_read_coo(str(p))
+    assert coo["row"].tolist() == [0, 1] and coo["col"].tolist() == [0, 1] and coo["val"].tolist() == [4.0, 0.5]
+    # a short file still reports the premature end
+    p.write_text("%%MatrixMarket matrix coordinate real general\n3 3 3\n1 1 4.0\n2 2 7\n")
+    with pytest.raises(sm.SmvpError) as e:
+        sm.mm_read_coo(str(p))
+    assert e.value.code == sm.MM_PREMATURE_EOF
