@@ -133,8 +133,8 @@ int smvp_device_count(int *count);
 int smvp_device_info(int device, char *name, size_t name_cap, int *compute_units,
                      size_t *hbm_bytes);
 
-/* CSR kernel families (smvp_csr_set_kernel).  AUTO picks by row-length
- * statistics at create time. */
+/* CSR kernel families (smvp_csr_set_kernel).  AUTO picks STREAM, or STREAM_CARRY when some row is
+ * longer than 16384 entries. */
 enum {
     SMVP_CSR_KERNEL_AUTO = 0,
     SMVP_CSR_KERNEL_VECTOR = 1,      /* one (sub-)wavefront per row, __shfl_down sums */

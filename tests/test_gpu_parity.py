@@ -124,10 +124,10 @@ def test_stream_kernel_is_bitwise_serial_on_short_rows(torch):
 
 
 def test_auto_plan_choice(torch):
-    """AUTO: owner-completes tiles by default, the carry form when some row is extremely long, vector for long means."""
+    """AUTO: owner-completes tiles by default, the carry form when some row is extremely long; never the vector kernel."""
     rng = np.random.default_rng(11)
     for lens, want in (([5] * 3000, sm.CSR_KERNEL_STREAM), ([3] * 500 + [40000] + [2] * 500, sm.CSR_KERNEL_STREAM_CARRY),
-                       ([128] * 300, sm.CSR_KERNEL_VECTOR)):
+                       ([128] * 300, sm.CSR_KERNEL_STREAM)):
         row_ptr, col_ind, val = csr_from_lengths(rng, lens, 50000)
         A = sm.CsrMatrix(len(lens), 50000, row_ptr, col_ind, val)
         assert A.get_kernel()[0] == want
