@@ -205,8 +205,8 @@ void choose_csr_kernel(smvp_csr *h, int kernel, int param)
         h->lanes_per_row = param > 0 ? param : pow2_at_least(mean);
     } else {
         int tile = param > 0 ? param : 0;
-        if (tile == 0)
-            tile = 1024;  // measured 1-4 % ahead of 2048 on memplus x944 and pwt x459 (MI355X)
+        if (tile == 0)  // 1024 measured 1-4 % ahead of 2048 on memplus x944 and pwt x459; 256-entry tiles when
+            tile = (kernel == SMVP_CSR_KERNEL_STREAM && h->nnz < 512 * 1024) ? 256 : 1024;  // 1024 would leave CUs idle
         h->vpt = tile / smvp::kStreamBlock;
     }
 }
@@ -299,8 +299,9 @@ extern "C" int smvp_csr_set_kernel(smvp_csr_t *h, int kernel, int param)
     if (kernel == SMVP_CSR_KERNEL_VECTOR && param != 0 &&
         (param < 2 || param > 64 || (param & (param - 1)) != 0))
         return smvp::fail(SMVP_ERR_INVALID, "lanes per row must be a power of two in [2, 64]");
-    if ((kernel == SMVP_CSR_KERNEL_STREAM || kernel == SMVP_CSR_KERNEL_STREAM_CARRY) && param != 0 && param != 1024 &&
-        param != 2048)
+    if (kernel == SMVP_CSR_KERNEL_STREAM && param != 0 && param != 256 && param != 1024 && param != 2048)
+        return smvp::fail(SMVP_ERR_INVALID, "entries per tile must be 256, 1024 or 2048");
+    if (kernel == SMVP_CSR_KERNEL_STREAM_CARRY && param != 0 && param != 1024 && param != 2048)
         return smvp::fail(SMVP_ERR_INVALID, "entries per tile must be 1024 or 2048");
     HIP_TRY(hipSetDevice(h->device));
     choose_csr_kernel(h, kernel, param);

@@ -231,13 +231,19 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     int c[VPT];
     double v[VPT];
     if (whole) {
+        if constexpr (VPT >= 4) {
 #pragma unroll
-        for (int k = 0; k < VPT; k += 4)
-            *reinterpret_cast<int4 *>(&c[k]) = *reinterpret_cast<const int4 *>(col_ind + j0 + k);
-        if (!UNIT) {
+            for (int k = 0; k < VPT; k += 4)
+                *reinterpret_cast<int4 *>(&c[k]) = *reinterpret_cast<const int4 *>(col_ind + j0 + k);
+            if (!UNIT) {
 #pragma unroll
-            for (int k = 0; k < VPT; k += 2)
-                *reinterpret_cast<double2 *>(&v[k]) = *reinterpret_cast<const double2 *>(val + j0 + k);
+                for (int k = 0; k < VPT; k += 2)
+                    *reinterpret_cast<double2 *>(&v[k]) = *reinterpret_cast<const double2 *>(val + j0 + k);
+            }
+        } else {  // VPT == 1: 256-entry tiles for matrices too small to fill the chip with 1024-entry ones
+            c[0] = col_ind[j0];
+            if (!UNIT)
+                v[0] = val[j0];
         }
     }
     const int rlo = tile_row[b];
@@ -283,9 +289,13 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
         if (over0)
             po = (UNIT ? 1.0 : val[e + t]) * x[col_ind[e + t]];
     }
+    if constexpr (VPT >= 2) {
 #pragma unroll
-    for (int k = 0; k < VPT; k += 2)
-        *reinterpret_cast<double2 *>(&prod[t * VPT + k]) = make_double2(p[k], p[k + 1]);
+        for (int k = 0; k < VPT; k += 2)
+            *reinterpret_cast<double2 *>(&prod[t * VPT + k]) = make_double2(p[k], p[k + 1]);
+    } else {
+        prod[t] = p[0];
+    }
     if (over0)
         prod[e - lo + t] = po;
     if (!giant)  // rare: the last row runs more than one block width past the tile
@@ -517,14 +527,17 @@ hipError_t launch_csr_vector(int lanes_per_row, const int *row_ptr, const int *c
     return hipGetLastError();
 }
 
-static int tile_group()
+// Tiles per XCD turn for a launch of `ntiles` tiles: kStreamTileGroup, smaller for small matrices so that
+// the grid (rounded up to a multiple of 8 * group) is not mostly empty blocks.
+static int tile_group(int ntiles)
 {
     static const int g = [] {
         const char *e = getenv("SMVP_TILE_GROUP");  // development switch
         const int v = e ? atoi(e) : kStreamTileGroup;
         return v >= 1 ? v : 1;
     }();
-    return g;
+    const int fit = ntiles / 64;
+    return fit < 1 ? 1 : (fit < g ? fit : g);
 }
 
 hipError_t launch_csr_stream(int vpt, const int *row_ptr, const int *col_ind, const double *val,
@@ -533,7 +546,7 @@ hipError_t launch_csr_stream(int vpt, const int *row_ptr, const int *col_ind, co
 {
     if (rows <= 0)
         return hipSuccess;
-    const int group = tile_group();
+    const int group = tile_group(ntiles);
     const dim3 grid((unsigned)((ntiles + 8 * group - 1) / (8 * group)) * 8u * group);
     switch (vpt) {
     case 4:
@@ -564,12 +577,16 @@ hipError_t launch_csr_stream_owner(int vpt, bool unit_values, const int *row_ptr
 {
     if (rows <= 0)
         return hipSuccess;
-    const int group = tile_group();
+    const int group = tile_group(ntiles);
     const dim3 grid((unsigned)((ntiles + 8 * group - 1) / (8 * group)) * 8u * group);
 #define SMVP_OWNER(V, U)                                                                                          \
     hipLaunchKernelGGL((csr_stream_owner<V, U>), grid, dim3(kStreamBlock), 0, stream, row_ptr, col_ind, val, x, y, \
                        tile_row, tile_next, rows, nnz, ntiles, group)
-    if (vpt == 4 && !unit_values)
+    if (vpt == 1 && !unit_values)
+        SMVP_OWNER(1, false);
+    else if (vpt == 1 && unit_values)
+        SMVP_OWNER(1, true);
+    else if (vpt == 4 && !unit_values)
         SMVP_OWNER(4, false);
     else if (vpt == 8 && !unit_values)
         SMVP_OWNER(8, false);

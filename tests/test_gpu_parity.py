@@ -26,7 +26,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-9
 EXACT = {"ibm32.mtx", "curtis54.mtx", "pwt.mtx", "pdp08-pg4.mtx"}
 
-CSR_VARIANTS = [(sm.CSR_KERNEL_STREAM, 1024), (sm.CSR_KERNEL_STREAM, 2048),
+CSR_VARIANTS = [(sm.CSR_KERNEL_STREAM, 256), (sm.CSR_KERNEL_STREAM, 1024), (sm.CSR_KERNEL_STREAM, 2048),
                 (sm.CSR_KERNEL_STREAM_CARRY, 1024), (sm.CSR_KERNEL_STREAM_CARRY, 2048)] + \
                [(sm.CSR_KERNEL_VECTOR, t) for t in (2, 4, 8, 16, 32, 64)]
 
@@ -110,6 +110,8 @@ def test_stream_kernel_is_bitwise_serial_on_short_rows(torch):
     x = np.random.default_rng(1).random(n)
     ref = ob.csr_spmv(row_ptr, col_ind, val, x)
     lens = np.diff(row_ptr)
+    y = gpu_csr(torch, m, n, row_ptr, col_ind, val, x, sm.CSR_KERNEL_STREAM, 256)
+    assert np.array_equal(y[lens <= 32], ref[lens <= 32])
     for tile in (1024, 2048):
         # owner form: wherever the row lies, also across a tile edge
         y = gpu_csr(torch, m, n, row_ptr, col_ind, val, x, sm.CSR_KERNEL_STREAM, tile)
@@ -126,7 +128,7 @@ def test_stream_kernel_is_bitwise_serial_on_short_rows(torch):
 def test_auto_plan_choice(torch):
     """AUTO: owner-completes tiles by default, the carry form when some row is extremely long; never the vector kernel."""
     rng = np.random.default_rng(11)
-    for lens, want in (([5] * 3000, sm.CSR_KERNEL_STREAM), ([3] * 500 + [40000] + [2] * 500, sm.CSR_KERNEL_STREAM_CARRY),
+    for lens, want in (([5] * 300000, sm.CSR_KERNEL_STREAM), ([3] * 500 + [40000] + [2] * 500, sm.CSR_KERNEL_STREAM_CARRY),
                        ([128] * 300, sm.CSR_KERNEL_STREAM)):
         row_ptr, col_ind, val = csr_from_lengths(rng, lens, 50000)
         A = sm.CsrMatrix(len(lens), 50000, row_ptr, col_ind, val)
