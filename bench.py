@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--copies", type=int, default=944, help="memplus_tiled: diagonal blocks (944 -> 16.76 M rows)")
     ap.add_argument("--rows-log2", type=int, default=24, help="memplus_shaped: total rows = 2^k")
     ap.add_argument("--rows", type=int, default=10_000_000, help="uniform32: total rows (BASELINE config 4)")
+    ap.add_argument("--format", default="csr", choices=["csr", "tjds"],
+                    help="storage format of the timed product (the other one is reported in extra at N = 1)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "vector", "stream-carry"])
     ap.add_argument("--kernel-param", type=int, default=0)
     ap.add_argument("--x", default="ones", choices=["ones", "random"])
@@ -171,12 +173,23 @@ def host_check(blk, x_host, got):
 
 def measure_csr(torch, dist, sm, sharding_mod, blk, args, world, local_rank, rank, steps, warmup, collective):
     """Upload the block, check it, time `steps` products (+ all-gather), then the kernel alone."""
-    d_row_ptr = torch.from_numpy(blk["row_ptr"]).cuda()
-    d_col_ind = torch.from_numpy(blk["col_ind"]).cuda()
-    d_val = torch.from_numpy(blk["val"]).cuda()
-    A = sm.CsrMatrix(blk["rows"], blk["cols_total"], d_row_ptr, d_col_ind, d_val, device=local_rank)
-    if args.kernel != "auto" or args.kernel_param:
-        A.set_kernel({"auto": 0, "vector": 1, "stream": 2, "stream-carry": 3}[args.kernel], args.kernel_param)
+    fmt = getattr(args, "format", "csr")
+    if fmt == "csr":
+        d_row_ptr = torch.from_numpy(blk["row_ptr"]).cuda()
+        d_col_ind = torch.from_numpy(blk["col_ind"]).cuda()
+        d_val = torch.from_numpy(blk["val"]).cuda()
+        A = sm.CsrMatrix(blk["rows"], blk["cols_total"], d_row_ptr, d_col_ind, d_val, device=local_rank)
+        if args.kernel != "auto" or args.kernel_param:
+            A.set_kernel({"auto": 0, "vector": 1, "stream": 2, "stream-carry": 3}[args.kernel], args.kernel_param)
+    else:   # TJDS of this rank's row block, built on the GPU from the block's entries
+        coo = np.zeros(blk["nnz"], dtype=sm.COO_DTYPE)
+        coo["row"] = np.repeat(np.arange(blk["rows"], dtype=np.int32), np.diff(blk["row_ptr"]))
+        coo["col"], coo["val"] = blk["col_ind"], blk["val"]
+        d_coo = torch.from_numpy(coo.view(np.uint8)).cuda()
+        del coo
+        d_row_ptr = d_col_ind = d_val = None
+        A = sm.TjdsMatrix(sm.tjds_from_coo_device(d_coo, blk["rows"], blk["cols_total"], blk["nnz"]), device=local_rank)
+        del d_coo
     kernel_name, alg_bytes = A.describe()
 
     x_host = np.ones(blk["cols_total"]) if args.x == "ones" else np.random.default_rng(67890).random(blk["cols_total"])
@@ -188,13 +201,19 @@ def measure_csr(torch, dist, sm, sharding_mod, blk, args, world, local_rank, ran
     stream = torch.cuda.current_stream()
     gather = collective and (world > 1 or dist.is_initialized())
 
+    if fmt == "tjds":
+        A.set_x(d_x, stream=stream)      # the operand permutation is set-up, like main-cli.c:907-923
+
     def spmv_only():
-        A.spmv(d_x, d_y, stream=stream)
+        if fmt == "csr":
+            A.spmv(d_x, d_y, stream=stream)
+        else:
+            A.spmv(d_y, stream=stream)
 
     bounds = blk["bounds"]
 
     def step():
-        A.spmv(d_x, d_y, stream=stream)
+        spmv_only()
         if gather:      # equal row blocks: one all_gather_into_tensor straight into the full y
             sharding_mod.allgather_y(dist, d_y, d_y_full, bounds)
 
@@ -277,7 +296,7 @@ def roofline_of(res, workload=None):
     r = {"bound": "hbm", "kernel": res["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
          "alg_bytes_per_launch": res["alg_bytes_local"], "ms_per_launch": round(res["kernel_ms"], 5),
-         "note": "one launch per product, HIP events on the launch stream"}
+         "note": "per product (CSR: one launch; TJDS: products kernel + row sums), HIP events on the launch stream"}
     rec = recorded_traffic(workload, res["kernel"], res["alg_bytes_local"]) if workload else None
     if rec:
         r["traffic"] = rec[0]
@@ -334,7 +353,7 @@ def main():
         extra["y_bytes_gathered"] = blk["rows_total"] * 8
 
     # ------------------------------------------------------------ TJDS beside it (same matrix)
-    if not args.no_tjds and world == 1:
+    if not args.no_tjds and world == 1 and args.format == "csr":
         try:
             t0 = time.perf_counter()
             coo = np.zeros(blk["nnz"], dtype=sm.COO_DTYPE)
@@ -438,7 +457,7 @@ def main():
                 samples[name] = {"error": str(ex)}
         extra["sample_matrices"] = samples
 
-    headline_roofline = roofline_of(res, blk["name"] + ", CSR, x=%s" % args.x)
+    headline_roofline = roofline_of(res, blk["name"] + ", %s, x=%s" % (args.format.upper(), args.x))
     res["A"].close()
     del res["keep"], res["d_x"], res["d_y"]
     torch.cuda.empty_cache()
@@ -463,14 +482,14 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "fp64 CSR SpMV GFLOP/s (2*nnz flop per product; achieved HBM GB/s in roofline)",
+            "metric": "fp64 %s SpMV GFLOP/s (2*nnz flop per product; achieved HBM GB/s in roofline)" % args.format.upper(),
             "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(res["wall_per_step"] * 1e3, 5), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": blk["name"] + ", CSR, x=%s" % args.x +
+            "config": {"workload": blk["name"] + ", %s, x=%s" % (args.format.upper(), args.x) +
                        (", %d row blocks + %s all-gather of y" % (world, "RCCL" if backend == "nccl" else backend)
                         if world > 1 and not args.no_allgather else ""),
-                       "format": "csr", "kernel": res["kernel"], "nnz": int(res["nnz_total"]),
+                       "format": args.format, "kernel": res["kernel"], "nnz": int(res["nnz_total"]),
                        "rows": blk["rows_total"], "sharding": "row-block x%d" % world},
             "roofline": headline_roofline, "cpu_baseline": cpu, "extra": extra,
         }

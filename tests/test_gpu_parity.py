@@ -666,3 +666,18 @@ def test_sharded_rejects_bad_gpu_counts(torch):
         assert ob.fmt_g(y) == ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_1615284655.txt"))
         y, ms, st = sm.tjds_compute(coo, m, n, iters=5, ngpus=2)
         assert ob.fmt_g(y) == ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_1615284655.txt"))
+
+
+def test_bench_script_tjds_format(torch):
+    import json
+    import sys
+
+    from conftest import ROOT
+
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--format", "tjds", "--copies", "8", "--steps", "3",
+                        "--warmup", "1", "--no-random-model", "--no-samples", "--no-cpu-baseline"],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert j["config"]["format"] == "tjds" and "TJDS" in j["metric"] and "products" in j["roofline"]["kernel"]
+    assert j["extra"]["full_size_parity"]["y_equals_tiled_reference_memplus_y"] and j["value"] > 0
