@@ -209,6 +209,9 @@ int smvp_sharded_set_x(smvp_sharded_t *h, const double *x_host); /* NULL = ones;
 /* local products on every GPU (+ the all-gather); asynchronous.  timed != 0 brackets it with an event pair per GPU */
 int smvp_sharded_spmv(smvp_sharded_t *h, int allgather, int timed);
 int smvp_sharded_synchronize(smvp_sharded_t *h, double *ms_of_last_timed_product); /* max over the GPUs */
+/* power iteration: the gathered y (optionally divided by its largest magnitude) becomes x on every GPU;
+ * call between two smvp_sharded_spmv(h, 1, ..), after which the all-gather is what feeds the next product */
+int smvp_sharded_feed_back(smvp_sharded_t *h, int normalize);
 int smvp_sharded_get_y(smvp_sharded_t *h, int slot, int gathered, double *y_host);
 int smvp_sharded_info(const smvp_sharded_t *h, int *ngpus, int *rows_per_gpu);
 void smvp_sharded_destroy(smvp_sharded_t *h);
@@ -221,6 +224,9 @@ typedef struct smvp_run_opts {
     int tjds_ref_quirks;/* 1: reproduce the reference's defective TJDS output */
     int convert_on_device; /* 1: COO -> CSR / TJDS on the GPU (smvp_*_from_coo_device), 0: on the host */
     int ngpus;          /* 0 or 1: one GPU (`device`); N > 1: row blocks on GPUs 0..N-1 + RCCL all-gather of y */
+    int iterate;        /* 1: power iteration, x_{k+1} = A x_k for `iters` steps -- the product the assignment asked
+                           for (comment at main-cli.c:401); square matrices; y = the last iterate; each step timed */
+    int normalize;      /* with iterate: divide every iterate by its largest magnitude (keeps 1000 steps finite) */
     const double *x;    /* host operand, NULL = all ones (main-cli.c:368-369) */
 } smvp_run_opts_t;
 void smvp_run_opts_default(smvp_run_opts_t *o);

@@ -52,6 +52,9 @@ void orc_csr_build_literal(const orc_coo *coo, int rows, int nnz,
 void orc_csr_spmv(int rows, const int *row_ptr, const int *col_ind, const double *val,
                   const double *x, double *y);
 
+void orc_csr_iterate(int rows, const int *row_ptr, const int *col_ind, const double *val,
+                     const double *x0, int iters, int normalize, double *y);
+
 /* TJDS ----------------------------------------------------------------- */
 /* perm[cols], start_pos[max_diag+1 needed, caller gives rows+2], row_ind[nnz],
  * val[nnz].  *num_diag = D (longest column); *ref_num_tjdiag = the count the

@@ -19,7 +19,7 @@
  *     recognised and refused: out of scope for the GPU engine.
  *   - libpopt is not used (absent from the image): getopt_long("+...") gives the
  *     same POSIX ordering rule.
- * Additive flags: --device N, --gpus N, --ref-quirks, --device-convert, --csr-kernel auto|vector|stream|stream-carry,
+ * Additive flags: --device N, --gpus N, --iterate, --normalize, --ref-quirks, --device-convert, --csr-kernel auto|vector|stream|stream-carry,
  * --quiet-arrays is implied (the reference's SMVP_CSR_DEBUG array dumps,
  * main-cli.c:374-394, are not printed).
  */
@@ -42,14 +42,14 @@
 #define RESET "\x1b[0m"
 
 enum { ALG_NONE = 0, ALG_CSR = 1 << 1, ALG_TJDS = 1 << 2, ALG_CISR = 1 << 3, ALG_ALL = 256 };
-enum { OPT_DEVICE = 1000, OPT_QUIRKS, OPT_KERNEL, OPT_USAGE, OPT_DEVCONV, OPT_GPUS };
+enum { OPT_DEVICE = 1000, OPT_QUIRKS, OPT_KERNEL, OPT_USAGE, OPT_DEVCONV, OPT_GPUS, OPT_ITERATE, OPT_NORMALIZE };
 
 static void usage(FILE *to, const char *prog)
 {
     fprintf(to,
             "Usage: %s [-acgt?] [-a|--all-algs] [-c|--csr] [-g|--cisr-gen] [-t|--tjds]\n"
             "        [-n|--number=1000] [-s|--slots=16] [-d|--dir=./] [--device=0] [--gpus=1]\n"
-            "        [--ref-quirks] [--device-convert] [--csr-kernel=auto|vector|stream|stream-carry]\n"
+            "        [--ref-quirks] [--iterate] [--normalize] [--device-convert] [--csr-kernel=auto|vector|stream|stream-carry]\n"
             "        [-?|--help] [--usage]\n"
             "        [OPTIONS] <file>\n",
             prog);
@@ -67,6 +67,8 @@ static void help(const char *prog)
     puts("  -d, --dir=./             Output folder for reports.");
     puts("      --device=0           HIP device ordinal.");
     puts("      --gpus=1             Shard the matrix by row blocks over this many GPUs (RCCL all-gather of y).");
+    puts("      --iterate            Power iteration: feed each result back as the next operand (x <- A x, n times).");
+    puts("      --normalize          --iterate, and divide every iterate by its largest magnitude.");
     puts("      --ref-quirks         Reproduce the reference v0.6.4 TJDS output, defects included.");
     puts("      --device-convert     Build CSR / TJDS from the loaded entries on the GPU instead of the host.");
     puts("      --csr-kernel=auto    CSR kernel family: auto, vector, stream, stream-carry.");
@@ -139,10 +141,11 @@ int main(int argc, char *argv[])
         {"usage", no_argument, NULL, OPT_USAGE},   {"device", required_argument, NULL, OPT_DEVICE},
         {"ref-quirks", no_argument, NULL, OPT_QUIRKS}, {"csr-kernel", required_argument, NULL, OPT_KERNEL},
         {"device-convert", no_argument, NULL, OPT_DEVCONV}, {"gpus", required_argument, NULL, OPT_GPUS},
+        {"iterate", no_argument, NULL, OPT_ITERATE}, {"normalize", no_argument, NULL, OPT_NORMALIZE},
         {NULL, 0, NULL, 0}};
     const char *prog = "smvp-toolkit-cli";
     int alg_mode = ALG_NONE, calc_iter = 1000, cisr_slots = 16, device = 0, quirks = 0;
-    int csr_kernel = SMVP_CSR_KERNEL_AUTO, device_convert = 0, ngpus = 1;
+    int csr_kernel = SMVP_CSR_KERNEL_AUTO, device_convert = 0, ngpus = 1, iterate = 0, normalize = 0;
     const char *report_dir = "";
 
     if (argc < 2) { /* main-cli.c:1267-1271 */
@@ -201,6 +204,12 @@ int main(int argc, char *argv[])
             break;
         case OPT_DEVCONV:
             device_convert = 1;
+            break;
+        case OPT_ITERATE:
+            iterate = 1;
+            break;
+        case OPT_NORMALIZE:
+            iterate = normalize = 1;
             break;
         case OPT_GPUS:
             if (parse_int(optarg, &v) != 0 || v < 1)
@@ -284,6 +293,9 @@ int main(int argc, char *argv[])
 
     printf(CYAN "[DATA]\tNon-zero numbers contained in matrix: " RESET "%d\n", nnz);
     printf(CYAN "[DATA]\tVector operand in use: " RESET "Ones vector with dimensions [%d, %d]\n", rows, 1);
+    if (iterate)
+        printf(CYAN "[DATA]\tPower iteration: " RESET "each result is the next operand%s\n",
+               normalize ? ", scaled to largest magnitude 1" : "");
 
     if (alg_mode & ALG_CISR)
         die("CISR COE generation targets an FPGA flow and is not part of the MI355X engine.");
@@ -310,6 +322,8 @@ int main(int argc, char *argv[])
     opts.tjds_ref_quirks = quirks;
     opts.convert_on_device = device_convert;
     opts.ngpus = ngpus;
+    opts.iterate = iterate;
+    opts.normalize = normalize;
     smvp_time_stats_t st;
     char path[4096];
 

@@ -688,6 +688,8 @@ namespace {
 // Scope guard for the scratch the two entry points allocate.
 struct RunScratch {
     double *d_x = nullptr, *d_y = nullptr;
+    double *d_result = nullptr;                          // where the last product was written (d_x or d_y when iterating)
+    unsigned long long *d_norm = nullptr;                // scratch of the normalisation
     void *d_coo = nullptr;                               // convert_on_device: the uploaded COO
     int *d_i0 = nullptr, *d_i1 = nullptr, *d_i2 = nullptr;  // ... and the arrays built from it
     double *d_v = nullptr;
@@ -699,6 +701,8 @@ struct RunScratch {
     {
         for (hipEvent_t e : ev)
             (void)hipEventDestroy(e);
+        if (d_norm)
+            (void)hipFree(d_norm);
         if (d_x)
             (void)hipFree(d_x);
         if (d_y)
@@ -717,7 +721,9 @@ int prepare_run(RunScratch &s, int rows, int cols, int iters, const smvp_run_opt
 {
     HIP_TRY(hipStreamCreate(&s.stream));
     HIP_TRY(hipMalloc((void **)&s.d_x, sizeof(double) * (size_t)std::max(std::max(cols, rows), 1)));
-    HIP_TRY(hipMalloc((void **)&s.d_y, sizeof(double) * (size_t)std::max(rows, 1)));
+    HIP_TRY(hipMalloc((void **)&s.d_y, sizeof(double) * (size_t)std::max(std::max(cols, rows), 1)));
+    HIP_TRY(hipMalloc((void **)&s.d_norm, sizeof(unsigned long long)));
+    s.d_result = s.d_y;
     if (o->x) {
         HIP_TRY(hipMemcpy(s.d_x, o->x, sizeof(double) * (size_t)cols, hipMemcpyHostToDevice));
     } else {
@@ -750,7 +756,14 @@ int finish_run(RunScratch &s, int rows, int iters, double *y, double *time_each_
     if (stats)
         smvp_time_stats(time_each_ms, iters, stats);
     if (rows > 0)
-        HIP_TRY(hipMemcpy(y, s.d_y, sizeof(double) * (size_t)rows, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(y, s.d_result, sizeof(double) * (size_t)rows, hipMemcpyDeviceToHost));
+    return SMVP_OK;
+}
+
+int check_iterate(const smvp_run_opts_t *o, int rows, int cols)
+{
+    if (o->iterate && rows != cols)
+        return smvp::fail(SMVP_ERR_INVALID, "power iteration needs a square matrix (%d x %d given)", rows, cols);
     return SMVP_OK;
 }
 
@@ -783,6 +796,8 @@ static int sharded_compute(bool tjds, const smvp_coo_t *coo, int rows, int cols,
         rc = smvp_sharded_spmv(h, 1, 1);
         if (rc == SMVP_OK)
             rc = smvp_sharded_synchronize(h, &time_each_ms[i]);
+        if (rc == SMVP_OK && o->iterate && (i + 1 < iters || o->normalize))
+            rc = smvp_sharded_feed_back(h, o->normalize);  // the gathered y is the next operand on every GPU
     }
     if (rc == SMVP_OK)
         rc = smvp_sharded_get_y(h, 0, 1, y);
@@ -801,6 +816,8 @@ extern "C" int smvp_csr_compute(const smvp_coo_t *coo, int rows, int cols, int n
     const smvp_run_opts_t *o = opts ? opts : &def;
     if (iters < 1 || rows < 0 || cols < 0 || nnz < 0 || (rows > 0 && !y))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_compute: bad argument");
+    if (int rc = check_iterate(o, rows, cols))
+        return rc;
     if (o->ngpus > 1)
         return sharded_compute(false, coo, rows, cols, nnz, iters, o, y, time_each_ms, stats);
     if (int rc = usable_device(o->device))
@@ -835,15 +852,21 @@ extern "C" int smvp_csr_compute(const smvp_coo_t *coo, int rows, int cols, int n
     if (int rc = prepare_run(s, rows, cols, iters, o))
         return rc;
 
+    double *xc = s.d_x, *yc = s.d_y;
     for (int i = 0; i < iters; ++i) {
         // the reference clears y before every product, outside its timed window
         // (main-cli.c:405); the CSR kernels overwrite y, the clear is kept so a
         // kernel that skipped a row could not hide behind the previous result
-        HIP_TRY(hipMemsetAsync(s.d_y, 0, sizeof(double) * (size_t)std::max(rows, 1), s.stream));
+        HIP_TRY(hipMemsetAsync(yc, 0, sizeof(double) * (size_t)std::max(rows, 1), s.stream));
         HIP_TRY(hipEventRecord(s.ev[(size_t)2 * i], s.stream));
-        if (int rc = smvp_csr_spmv(s.csr, s.d_x, s.d_y, s.stream))
+        if (int rc = smvp_csr_spmv(s.csr, xc, yc, s.stream))
             return rc;
+        if (o->iterate && o->normalize)
+            HIP_TRY(smvp::launch_normalize_max(yc, rows, s.d_norm, s.stream));
         HIP_TRY(hipEventRecord(s.ev[(size_t)2 * i + 1], s.stream));
+        s.d_result = yc;
+        if (o->iterate)
+            std::swap(xc, yc);  // x_{k+1} = y_k
     }
     return finish_run(s, rows, iters, y, time_each_ms, stats);
 }
@@ -857,6 +880,10 @@ extern "C" int smvp_tjds_compute(const smvp_coo_t *coo, int rows, int cols, int 
     const smvp_run_opts_t *o = opts ? opts : &def;
     if (iters < 1 || rows < 0 || cols < 0 || nnz < 0 || (rows > 0 && !y))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_compute: bad argument");
+    if (int rc = check_iterate(o, rows, cols))
+        return rc;
+    if (o->iterate && o->tjds_ref_quirks)
+        return smvp::fail(SMVP_ERR_UNSUPPORTED, "ref-quirks TJDS indexes the operand by row: it has no meaning for a changing operand");
     if (o->ngpus > 1) {
         if (o->tjds_ref_quirks)
             return smvp::fail(SMVP_ERR_UNSUPPORTED, "ref-quirks TJDS is a whole-matrix artefact: use one GPU");
@@ -902,13 +929,22 @@ extern "C" int smvp_tjds_compute(const smvp_coo_t *coo, int rows, int cols, int 
     if (int rc = smvp_tjds_set_x(s.tjds, s.d_x, s.stream))  // main-cli.c:907-923, setup
         return rc;
 
+    double *xc = s.d_x, *yc = s.d_y;
     for (int i = 0; i < iters; ++i) {
-        if (int rc = smvp_tjds_zero_y(s.tjds, s.d_y, s.stream))  // main-cli.c:1008, outside the window
+        if (int rc = smvp_tjds_zero_y(s.tjds, yc, s.stream))  // main-cli.c:1008, outside the window
             return rc;
         HIP_TRY(hipEventRecord(s.ev[(size_t)2 * i], s.stream));
-        if (int rc = smvp_tjds_spmv(s.tjds, s.d_y, s.stream))
+        if (o->iterate && i > 0)  // a new operand: its permutation is part of this product
+            if (int rc = smvp_tjds_set_x(s.tjds, xc, s.stream))
+                return rc;
+        if (int rc = smvp_tjds_spmv(s.tjds, yc, s.stream))
             return rc;
+        if (o->iterate && o->normalize)
+            HIP_TRY(smvp::launch_normalize_max(yc, rows, s.d_norm, s.stream));
         HIP_TRY(hipEventRecord(s.ev[(size_t)2 * i + 1], s.stream));
+        s.d_result = yc;
+        if (o->iterate)
+            std::swap(xc, yc);
     }
     return finish_run(s, rows, iters, y, time_each_ms, stats);
 }

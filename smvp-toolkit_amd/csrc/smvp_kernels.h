@@ -27,6 +27,7 @@ hipError_t launch_tjds_scatter(bool operand_by_row, const int *start_pos, const 
                                hipStream_t stream);
 hipError_t launch_tjds_permute(const int *perm, const double *x, double *x_perm, int cols, hipStream_t stream);
 hipError_t launch_find_out_of_range(const int *a, long long n, int limit, int *bad, hipStream_t stream);
+hipError_t launch_normalize_max(double *v, long long n, unsigned long long *scratch, hipStream_t stream);
 hipError_t launch_fill(double *p, double v, long long n, hipStream_t stream);
 
 }  // namespace smvp

@@ -491,6 +491,34 @@ __global__ __launch_bounds__(256) void find_out_of_range(const int *__restrict__
     }
 }
 
+// max |v[i]| as the bit pattern of a non-negative double (those order like unsigned integers); *bits = 0 first
+__global__ __launch_bounds__(256) void vector_absmax(const double *__restrict__ v, long long n,
+                                                      unsigned long long *__restrict__ bits)
+{
+    double m = 0.0;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const double a = fabs(v[i]);
+        m = a > m ? a : m;  // NaN entries are skipped
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_down(m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(bits, (unsigned long long)__double_as_longlong(m));
+}
+
+__global__ __launch_bounds__(256) void vector_divide(double *__restrict__ v, long long n,
+                                                      const unsigned long long *__restrict__ bits)
+{
+    const double m = __longlong_as_double((long long)*bits);
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && m > 0.0)
+        v[i] = v[i] / m;
+}
+
 __global__ __launch_bounds__(256) void fill_value(double *__restrict__ p, double v, long long n)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -640,6 +668,20 @@ hipError_t launch_find_out_of_range(const int *a, long long n, int limit, int *b
     const long long want = (n + 255) / 256;
     hipLaunchKernelGGL(find_out_of_range, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, stream, a, n,
                        limit, bad);
+    return hipGetLastError();
+}
+
+// v <- v / max|v| (left alone when the maximum is 0); scratch = one unsigned long long of device memory
+hipError_t launch_normalize_max(double *v, long long n, unsigned long long *scratch, hipStream_t stream)
+{
+    if (n <= 0)
+        return hipSuccess;
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess)
+        return e;
+    const long long want = (n + 255) / 256;
+    hipLaunchKernelGGL(vector_absmax, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, stream, v, n, scratch);
+    hipLaunchKernelGGL(vector_divide, dim3((unsigned)want), dim3(256), 0, stream, v, n, scratch);
     return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@
 // librccl is loaded with dlopen the first time more than zero GPUs are sharded,
 // so single-GPU runs neither link nor load it.
 #include "smvp_common.h"
+#include "smvp_kernels.h"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -80,6 +81,7 @@ struct smvp_sharded {
     std::vector<double *> d_x, d_y_local, d_y_full;
     std::vector<hipEvent_t> ev0, ev1;
     std::vector<ncclComm_t> comm;
+    std::vector<unsigned long long *> d_norm;
     Rccl *rccl = nullptr;
 };
 
@@ -98,6 +100,8 @@ extern "C" void smvp_sharded_destroy(smvp_sharded_t *h)
         for (auto *vec : {&h->d_x, &h->d_y_local, &h->d_y_full})
             if (g < (int)vec->size() && (*vec)[(size_t)g])
                 (void)hipFree((*vec)[(size_t)g]);
+        if (g < (int)h->d_norm.size() && h->d_norm[(size_t)g])
+            (void)hipFree(h->d_norm[(size_t)g]);
         if (g < (int)h->ev0.size() && h->ev0[(size_t)g])
             (void)hipEventDestroy(h->ev0[(size_t)g]);
         if (g < (int)h->ev1.size() && h->ev1[(size_t)g])
@@ -137,12 +141,14 @@ int sharded_common(smvp_sharded *h, int ngpus, const int *devices, int rows, int
     h->d_y_full.assign((size_t)ngpus, nullptr);
     h->ev0.assign((size_t)ngpus, nullptr);
     h->ev1.assign((size_t)ngpus, nullptr);
+    h->d_norm.assign((size_t)ngpus, nullptr);
     for (int g = 0; g < ngpus; ++g) {
         HIP_TRY(hipSetDevice(h->device[(size_t)g]));
         HIP_TRY(hipStreamCreate(&h->stream[(size_t)g]));
         HIP_TRY(hipEventCreate(&h->ev0[(size_t)g]));
         HIP_TRY(hipEventCreate(&h->ev1[(size_t)g]));
         HIP_TRY(hipMalloc((void **)&h->d_x[(size_t)g], sizeof(double) * (size_t)std::max(std::max(cols, rows), 1)));
+        HIP_TRY(hipMalloc((void **)&h->d_norm[(size_t)g], sizeof(unsigned long long)));
         HIP_TRY(hipMalloc((void **)&h->d_y_local[(size_t)g], sizeof(double) * (size_t)h->block));
         HIP_TRY(hipMalloc((void **)&h->d_y_full[(size_t)g], sizeof(double) * (size_t)h->block * (size_t)ngpus));
         HIP_TRY(hipMemset(h->d_y_local[(size_t)g], 0, sizeof(double) * (size_t)h->block));
@@ -275,6 +281,28 @@ extern "C" int smvp_sharded_spmv(smvp_sharded_t *h, int allgather, int timed)
             HIP_TRY(hipSetDevice(h->device[(size_t)g]));
             HIP_TRY(hipEventRecord(h->ev1[(size_t)g], h->stream[(size_t)g]));
         }
+    return SMVP_OK;
+}
+
+// Power iteration: on every GPU the gathered y (divided by its largest magnitude if asked) becomes x.  Every
+// GPU normalises its own full copy -- same data, same arithmetic, same result -- so no further exchange is needed.
+extern "C" int smvp_sharded_feed_back(smvp_sharded_t *h, int normalize)
+{
+    if (!h)
+        return smvp::fail(SMVP_ERR_INVALID, "null handle");
+    if (h->rows != h->cols)
+        return smvp::fail(SMVP_ERR_INVALID, "power iteration needs a square matrix");
+    for (int g = 0; g < h->n; ++g) {
+        const size_t i = (size_t)g;
+        HIP_TRY(hipSetDevice(h->device[i]));
+        if (normalize)
+            HIP_TRY(smvp::launch_normalize_max(h->d_y_full[i], h->rows, h->d_norm[i], h->stream[i]));
+        HIP_TRY(hipMemcpyAsync(h->d_x[i], h->d_y_full[i], sizeof(double) * (size_t)h->rows, hipMemcpyDeviceToDevice,
+                               h->stream[i]));
+        if (h->format == 1)
+            if (int rc = smvp_tjds_set_x(h->tjds[i], h->d_x[i], h->stream[i]))
+                return rc;
+    }
     return SMVP_OK;
 }
 

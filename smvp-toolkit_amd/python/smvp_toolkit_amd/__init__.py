@@ -34,7 +34,7 @@ class TimeStats(C.Structure):
 class RunOpts(C.Structure):
     _fields_ = [("device", C.c_int), ("csr_kernel", C.c_int), ("csr_param", C.c_int),
                 ("tjds_ref_quirks", C.c_int), ("convert_on_device", C.c_int), ("ngpus", C.c_int),
-                ("x", C.c_void_p)]
+                ("iterate", C.c_int), ("normalize", C.c_int), ("x", C.c_void_p)]
 
 
 class SmvpError(RuntimeError):
@@ -58,7 +58,7 @@ EXPORTS = [
     "smvp_tjds_create", "smvp_tjds_set_x", "smvp_tjds_zero_y", "smvp_tjds_spmv",
     "smvp_tjds_set_ref_quirks", "smvp_tjds_set_mode", "smvp_tjds_describe", "smvp_tjds_destroy",
     "smvp_csr_sharded_create", "smvp_tjds_sharded_create", "smvp_sharded_set_x", "smvp_sharded_spmv",
-    "smvp_sharded_synchronize", "smvp_sharded_get_y", "smvp_sharded_info", "smvp_sharded_destroy",
+    "smvp_sharded_synchronize", "smvp_sharded_feed_back", "smvp_sharded_get_y", "smvp_sharded_info", "smvp_sharded_destroy",
     "smvp_run_opts_default", "smvp_csr_compute", "smvp_tjds_compute",
     "smvp_time_stats", "smvp_generate_report_text",
     "smvp_synth_row_lengths", "smvp_synth_fill", "smvp_partition_rows",
@@ -100,6 +100,7 @@ def lib():
         L.smvp_sharded_spmv.argtypes = [vp, ci, ci]
         L.smvp_sharded_synchronize.argtypes = [vp, C.POINTER(C.c_double)]
         L.smvp_sharded_get_y.argtypes = [vp, ci, ci, vp]
+        L.smvp_sharded_feed_back.argtypes = [vp, ci]
         L.smvp_sharded_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
         L.smvp_sharded_destroy.argtypes = [vp]
         L.smvp_sharded_destroy.restype = None
@@ -422,6 +423,9 @@ class ShardedMatrix:
     def spmv(self, allgather=True, timed=True):
         _check(lib().smvp_sharded_spmv(self._h, int(allgather), int(timed)), "smvp_sharded_spmv")
 
+    def feed_back(self, normalize=False):
+        _check(lib().smvp_sharded_feed_back(self._h, int(normalize)), "smvp_sharded_feed_back")
+
     def synchronize(self):
         ms = C.c_double()
         _check(lib().smvp_sharded_synchronize(self._h, C.byref(ms)), "smvp_sharded_synchronize")
@@ -450,11 +454,13 @@ class ShardedMatrix:
 
 
 # ------------------------------------------------- reference-shaped entry points
-def _run_opts(device, csr_kernel, csr_param, ref_quirks, x, device_convert=False, ngpus=0):
+def _run_opts(device, csr_kernel, csr_param, ref_quirks, x, device_convert=False, ngpus=0, iterate=False,
+              normalize=False):
     o = RunOpts()
     lib().smvp_run_opts_default(C.byref(o))
     o.device, o.csr_kernel, o.csr_param, o.tjds_ref_quirks = device, csr_kernel, csr_param, int(ref_quirks)
     o.convert_on_device, o.ngpus = int(device_convert), int(ngpus)
+    o.iterate, o.normalize = int(iterate), int(normalize)
     keep = None
     if x is not None:
         keep = _arr(x, np.float64)
@@ -463,27 +469,28 @@ def _run_opts(device, csr_kernel, csr_param, ref_quirks, x, device_convert=False
 
 
 def csr_compute(coo, rows, cols, iters=1, device=0, kernel=CSR_KERNEL_AUTO, param=0, x=None, device_convert=False,
-                ngpus=0):
+                ngpus=0, iterate=False, normalize=False):
     """smvp_csr_compute: COO in, (y, per-iteration ms, TimeStats) out."""
     nnz = len(coo)
     coo = _arr(coo, COO_DTYPE)
     y = np.zeros(max(rows, 1), dtype=np.float64)
     ms = np.zeros(iters, dtype=np.float64)
     st = TimeStats()
-    o, keep = _run_opts(device, kernel, param, False, x, device_convert, ngpus)
+    o, keep = _run_opts(device, kernel, param, False, x, device_convert, ngpus, iterate, normalize)
     _check(lib().smvp_csr_compute(_p(coo), rows, cols, nnz, iters, C.byref(o), _p(y), _p(ms), C.byref(st)),
            "smvp_csr_compute")
     return y[:rows], ms, st
 
 
-def tjds_compute(coo, rows, cols, iters=1, device=0, ref_quirks=False, x=None, device_convert=False, ngpus=0):
+def tjds_compute(coo, rows, cols, iters=1, device=0, ref_quirks=False, x=None, device_convert=False, ngpus=0,
+                 iterate=False, normalize=False):
     """smvp_tjds_compute: COO in, (y, per-iteration ms, TimeStats) out."""
     nnz = len(coo)
     coo = _arr(coo, COO_DTYPE)
     y = np.zeros(max(rows, 1), dtype=np.float64)
     ms = np.zeros(iters, dtype=np.float64)
     st = TimeStats()
-    o, keep = _run_opts(device, CSR_KERNEL_AUTO, 0, ref_quirks, x, device_convert, ngpus)
+    o, keep = _run_opts(device, CSR_KERNEL_AUTO, 0, ref_quirks, x, device_convert, ngpus, iterate, normalize)
     _check(lib().smvp_tjds_compute(_p(coo), rows, cols, nnz, iters, C.byref(o), _p(y), _p(ms), C.byref(st)),
            "smvp_tjds_compute")
     return y[:rows], ms, st

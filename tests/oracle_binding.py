@@ -125,6 +125,15 @@ def csr_spmv(row_ptr, col_ind, val, x):
     return y
 
 
+def csr_iterate(row_ptr, col_ind, val, x0, iters, normalize=False):
+    rows = len(row_ptr) - 1
+    y = np.zeros(rows, dtype=np.float64)
+    lib().orc_csr_iterate(rows, _p(np.ascontiguousarray(row_ptr, dtype=np.int32)),
+                          _p(np.ascontiguousarray(col_ind, dtype=np.int32)), _p(np.ascontiguousarray(val, dtype=np.float64)),
+                          _p(np.ascontiguousarray(x0, dtype=np.float64)), iters, int(normalize), _p(y))
+    return y
+
+
 class Tjds:
     pass
 

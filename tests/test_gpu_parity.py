@@ -681,3 +681,59 @@ def test_bench_script_tjds_format(torch):
     j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert j["config"]["format"] == "tjds" and "TJDS" in j["metric"] and "products" in j["roofline"]["kernel"]
     assert j["extra"]["full_size_parity"]["y_equals_tiled_reference_memplus_y"] and j["value"] > 0
+
+
+# ------------------------------------------------------------- power iteration (parity unpinned: no reference output)
+@pytest.mark.parametrize("name", ["ibm32.mtx", "curtis54.mtx", "pwt.mtx"])
+def test_power_iteration_exact_on_pattern_matrices(torch, name):
+    """x <- A x three times on 0/1 matrices: every iterate is a vector of small integers, so any order is exact."""
+    m, n, coo = load(name)
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    want = ob.csr_iterate(row_ptr, col_ind, val, np.ones(n), 3)
+    y, ms, st = sm.csr_compute(coo, m, n, iters=3, iterate=True)
+    assert np.array_equal(y, want) and len(ms) == 3
+    y, ms, st = sm.tjds_compute(coo, m, n, iters=3, iterate=True)
+    assert np.array_equal(y, want)
+    # one iteration is the plain product
+    y, _, _ = sm.csr_compute(coo, m, n, iters=1, iterate=True)
+    assert np.array_equal(y, ob.csr_spmv(row_ptr, col_ind, val, np.ones(n)))
+
+
+def test_power_iteration_normalised_memplus(torch):
+    m, n, coo = load("memplus.mtx")
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    for iters in (1, 2, 5, 40):
+        want = ob.csr_iterate(row_ptr, col_ind, val, np.ones(n), iters, normalize=True)
+        for fn in (sm.csr_compute, sm.tjds_compute):
+            y, ms, st = fn(coo, m, n, iters=iters, iterate=True, normalize=True)
+            assert np.abs(y).max() == pytest.approx(1.0, abs=1e-12)
+            assert np.abs(y - want).max() <= 1e-9 * iters       # max-norm of both is 1
+    with pytest.raises(sm.SmvpError):                            # rectangular: no power iteration
+        sm.csr_compute(sm.make_coo([0], [1], [1.0]), 1, 2, iters=2, iterate=True)
+
+
+def test_sharded_power_iteration(torch):
+    m, n, coo = load("memplus.mtx")
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    want = ob.csr_iterate(row_ptr, col_ind, val, np.ones(n), 4, normalize=True)
+    for fmt in ("csr", "tjds"):
+        S = sm.ShardedMatrix(fmt, 1, m, n, coo=coo, csr=(row_ptr, col_ind, val))
+        S.set_x(None)
+        for _ in range(4):
+            S.spmv(allgather=True, timed=True)
+            S.synchronize()
+            S.feed_back(normalize=True)
+        S.synchronize()
+        assert np.abs(S.get_y() - want).max() <= 4e-9
+        S.close()
+
+
+def test_cli_iterate_flag(torch, tmp_path):
+    p = subprocess.run([sm.CLI_PATH, "-c", "-t", "--normalize", "-n", "5", "-d", str(tmp_path), ob.fixture_path("ibm32.mtx")],
+                       capture_output=True, text=True)
+    assert p.returncode == 0 and "Power iteration" in p.stdout
+    m, n, coo = load("ibm32.mtx")
+    want = ob.fmt_g(ob.csr_iterate(*sm.csr_from_coo(coo, m), np.ones(n), 5, normalize=True))
+    for f in os.listdir(tmp_path):
+        got = ob.report_y_lines(open(tmp_path / f).read())
+        assert all(abs(float(a) - float(b)) <= 2e-6 for a, b in zip(got, want))
