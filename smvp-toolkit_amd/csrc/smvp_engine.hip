@@ -352,7 +352,7 @@ extern "C" int smvp_csr_describe(const smvp_csr_t *h, char *kernel_name, size_t 
         if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
             snprintf(kernel_name, cap, "csr_vector_rows<%d>", h->lanes_per_row);
         else if (h->kernel == SMVP_CSR_KERNEL_STREAM)
-            snprintf(kernel_name, cap, h->unit_val ? "csr_stream_owner<%d, true>" : "csr_stream_owner<%d>", h->vpt);
+            snprintf(kernel_name, cap, h->unit_val ? "csr_stream_owner<%d, true>" : "csr_stream_owner<%d, false>", h->vpt);
         else
             snprintf(kernel_name, cap, "csr_stream_tiles<%d>", h->vpt);
     }
