@@ -737,3 +737,57 @@ def test_cli_iterate_flag(torch, tmp_path):
     for f in os.listdir(tmp_path):
         got = ob.report_y_lines(open(tmp_path / f).read())
         assert all(abs(float(a) - float(b)) <= 2e-6 for a, b in zip(got, want))
+
+
+# ------------------------------------------------------------- randomised structures (fuzz)
+def _fuzz_matrix(seed):
+    """Random shape and skew: power-law row lengths, empty rows, occasional huge rows, narrow or wide column range."""
+    rng = np.random.default_rng(9000 + seed)
+    rows = int(rng.integers(1, 4000))
+    cols = int(rng.integers(1, 6000))
+    style = seed % 5
+    if style == 0:
+        lens = rng.integers(0, 6, rows)
+    elif style == 1:
+        lens = np.minimum((rng.pareto(1.2, rows) * 3).astype(int), cols)
+    elif style == 2:
+        lens = np.where(rng.random(rows) < 0.7, 0, rng.integers(1, 40, rows))
+    elif style == 3:
+        lens = rng.integers(0, 3, rows)
+        lens[rng.integers(0, rows, 3)] = min(cols, int(rng.integers(1500, 5000)))
+    else:
+        lens = np.full(rows, min(cols, int(rng.integers(1, 70))))
+    lens = np.minimum(lens, cols).astype(np.int64)
+    row_ptr, col_ind, val = csr_from_lengths(rng, lens.tolist(), cols)
+    val *= 10.0 ** rng.integers(-8, 8, len(val))
+    x = rng.standard_normal(cols) * 10.0 ** rng.integers(-3, 3, cols)
+    return rows, cols, row_ptr, col_ind, val, x
+
+
+@pytest.mark.parametrize("seed", range(25))
+def test_fuzz_all_kernels_against_oracle(torch, seed):
+    rows, cols, row_ptr, col_ind, val, x = _fuzz_matrix(seed)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+    scale = row_scale(row_ptr, col_ind, val, x)
+    for kernel, param in CSR_VARIANTS:
+        y = gpu_csr(torch, rows, cols, row_ptr, col_ind, val, x, kernel, param)
+        assert_close(y, ref, scale)
+    lens = np.diff(row_ptr)
+    y = gpu_csr(torch, rows, cols, row_ptr, col_ind, val, x, sm.CSR_KERNEL_STREAM, 0)
+    assert np.array_equal(y[lens <= 32], ref[lens <= 32])          # short rows: the serial loop's bits
+    coo = sm.make_coo(np.repeat(np.arange(rows), lens), col_ind, val)
+    coo = coo[np.random.default_rng(seed).permutation(len(coo))]
+    for mode in (sm.TJDS_MODE_TWO_PHASE, sm.TJDS_MODE_ATOMIC):
+        T = sm.TjdsMatrix(sm.tjds_from_coo(coo, rows, cols))
+        T.set_mode(mode)
+        T.set_x(dev(torch, x))
+        dy = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+        T.zero_y(dy)
+        T.spmv(dy)
+        torch.cuda.synchronize()
+        assert_close(dy.cpu().numpy(), ref, scale)
+        T.close()
+    # device-built formats feed the same kernels
+    d_coo = _coo_to_device(torch, coo)
+    rp, ci, v = sm.csr_from_coo_device(d_coo, rows, cols, len(coo))
+    assert np.array_equal(rp.cpu().numpy(), row_ptr) and np.array_equal(ci.cpu().numpy(), col_ind)
