@@ -60,7 +60,7 @@ def assert_close(y, ref, scale, exact=False):
 def gpu_csr(torch, rows, cols, row_ptr, col_ind, val, x, kernel, param):
     A = sm.CsrMatrix(rows, cols, row_ptr, col_ind, val)
     A.set_kernel(kernel, param)
-    assert A.get_kernel() == (kernel, param)
+    assert A.get_kernel()[0] == kernel and (param == 0 or A.get_kernel()[1] == param)
     dx = dev(torch, x)
     dy = torch.full((max(rows, 1),), float("nan"), dtype=torch.float64, device="cuda")
     A.spmv(dx, dy)
