@@ -685,8 +685,11 @@ extern "C" void smvp_run_opts_default(smvp_run_opts_t *o)
 
 namespace {
 
+constexpr int kEventRing = 1024;
+
 // Scope guard for the scratch the two entry points allocate.
 struct RunScratch {
+    std::vector<double> ms;   // per-product times, filled as the event ring is drained
     double *d_x = nullptr, *d_y = nullptr;
     double *d_result = nullptr;                          // where the last product was written (d_x or d_y when iterating)
     unsigned long long *d_norm = nullptr;                // scratch of the normalisation
@@ -732,29 +735,39 @@ int prepare_run(RunScratch &s, int rows, int cols, int iters, const smvp_run_opt
         if (e != hipSuccess)
             return smvp::fail(SMVP_ERR_HIP, "fill launch failed: %s", hipGetErrorString(e));
     }
-    s.ev.resize((size_t)iters * 2);
-    for (auto &e : s.ev)
-        e = nullptr;
+    // a ring of event pairs, drained every kEventRing products: -n may be in the millions
+    s.ev.assign((size_t)std::min(iters, kEventRing) * 2, nullptr);
     for (auto &e : s.ev)
         HIP_TRY(hipEventCreate(&e));
+    s.ms.assign((size_t)iters, 0.0);
+    return SMVP_OK;
+}
+
+// events of product i
+inline hipEvent_t &ev_start(RunScratch &s, int i) { return s.ev[(size_t)2 * (i % kEventRing)]; }
+inline hipEvent_t &ev_stop(RunScratch &s, int i) { return s.ev[(size_t)2 * (i % kEventRing) + 1]; }
+
+// after product i has been enqueued: when the ring is full (or i is the last product) wait and read it out
+int drain_ring(RunScratch &s, int i, int iters)
+{
+    if ((i + 1) % kEventRing != 0 && i + 1 != iters)
+        return SMVP_OK;
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    for (int k = i - (i % kEventRing); k <= i; ++k) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev_start(s, k), ev_stop(s, k)));
+        s.ms[(size_t)k] = (double)ms;
+    }
     return SMVP_OK;
 }
 
 int finish_run(RunScratch &s, int rows, int iters, double *y, double *time_each_ms, smvp_time_stats_t *stats)
 {
     HIP_TRY(hipStreamSynchronize(s.stream));
-    std::vector<double> local;
-    if (!time_each_ms) {
-        local.resize((size_t)iters);
-        time_each_ms = local.data();
-    }
-    for (int i = 0; i < iters; ++i) {
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, s.ev[(size_t)2 * i], s.ev[(size_t)2 * i + 1]));
-        time_each_ms[i] = (double)ms;
-    }
+    if (time_each_ms)
+        memcpy(time_each_ms, s.ms.data(), sizeof(double) * (size_t)iters);
     if (stats)
-        smvp_time_stats(time_each_ms, iters, stats);
+        smvp_time_stats(s.ms.data(), iters, stats);
     if (rows > 0)
         HIP_TRY(hipMemcpy(y, s.d_result, sizeof(double) * (size_t)rows, hipMemcpyDeviceToHost));
     return SMVP_OK;
@@ -858,12 +871,14 @@ extern "C" int smvp_csr_compute(const smvp_coo_t *coo, int rows, int cols, int n
         // (main-cli.c:405); the CSR kernels overwrite y, the clear is kept so a
         // kernel that skipped a row could not hide behind the previous result
         HIP_TRY(hipMemsetAsync(yc, 0, sizeof(double) * (size_t)std::max(rows, 1), s.stream));
-        HIP_TRY(hipEventRecord(s.ev[(size_t)2 * i], s.stream));
+        HIP_TRY(hipEventRecord(ev_start(s, i), s.stream));
         if (int rc = smvp_csr_spmv(s.csr, xc, yc, s.stream))
             return rc;
         if (o->iterate && o->normalize)
             HIP_TRY(smvp::launch_normalize_max(yc, rows, s.d_norm, s.stream));
-        HIP_TRY(hipEventRecord(s.ev[(size_t)2 * i + 1], s.stream));
+        HIP_TRY(hipEventRecord(ev_stop(s, i), s.stream));
+        if (int rc = drain_ring(s, i, iters))
+            return rc;
         s.d_result = yc;
         if (o->iterate)
             std::swap(xc, yc);  // x_{k+1} = y_k
@@ -933,7 +948,7 @@ extern "C" int smvp_tjds_compute(const smvp_coo_t *coo, int rows, int cols, int 
     for (int i = 0; i < iters; ++i) {
         if (int rc = smvp_tjds_zero_y(s.tjds, yc, s.stream))  // main-cli.c:1008, outside the window
             return rc;
-        HIP_TRY(hipEventRecord(s.ev[(size_t)2 * i], s.stream));
+        HIP_TRY(hipEventRecord(ev_start(s, i), s.stream));
         if (o->iterate && i > 0)  // a new operand: its permutation is part of this product
             if (int rc = smvp_tjds_set_x(s.tjds, xc, s.stream))
                 return rc;
@@ -941,7 +956,9 @@ extern "C" int smvp_tjds_compute(const smvp_coo_t *coo, int rows, int cols, int 
             return rc;
         if (o->iterate && o->normalize)
             HIP_TRY(smvp::launch_normalize_max(yc, rows, s.d_norm, s.stream));
-        HIP_TRY(hipEventRecord(s.ev[(size_t)2 * i + 1], s.stream));
+        HIP_TRY(hipEventRecord(ev_stop(s, i), s.stream));
+        if (int rc = drain_ring(s, i, iters))
+            return rc;
         s.d_result = yc;
         if (o->iterate)
             std::swap(xc, yc);

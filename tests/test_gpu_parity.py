@@ -791,3 +791,13 @@ def test_fuzz_all_kernels_against_oracle(torch, seed):
     d_coo = _coo_to_device(torch, coo)
     rp, ci, v = sm.csr_from_coo_device(d_coo, rows, cols, len(coo))
     assert np.array_equal(rp.cpu().numpy(), row_ptr) and np.array_equal(ci.cpu().numpy(), col_ind)
+
+
+def test_many_iterations_use_the_event_ring(torch):
+    """-n beyond the ring of 1024 event pairs: every product still gets its own time."""
+    m, n, coo = load("ibm32.mtx")
+    y, ms, st = sm.csr_compute(coo, m, n, iters=2500)
+    assert len(ms) == 2500 and np.all(ms > 0) and st.time_total == pytest.approx(ms.sum())
+    assert ob.fmt_g(y) == ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_1615284655.txt"))
+    y, ms, st = sm.tjds_compute(coo, m, n, iters=1025)
+    assert len(ms) == 1025 and np.all(ms > 0)
