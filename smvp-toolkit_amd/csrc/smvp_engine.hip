@@ -663,8 +663,12 @@ extern "C" int smvp_device_info(int device, char *name, size_t name_cap, int *co
         return rc;
     hipDeviceProp_t p;
     HIP_TRY(hipGetDeviceProperties(&p, device));
-    if (name && name_cap)
-        snprintf(name, name_cap, "%s (%s)", p.name, p.gcnArchName);
+    if (name && name_cap) {
+        if (p.name[0])
+            snprintf(name, name_cap, "%s (%s)", p.name, p.gcnArchName);
+        else  // some driver stacks leave the marketing name empty
+            snprintf(name, name_cap, "%s", p.gcnArchName);
+    }
     if (compute_units)
         *compute_units = p.multiProcessorCount;
     if (hbm_bytes)
