@@ -801,3 +801,40 @@ def test_many_iterations_use_the_event_ring(torch):
     assert ob.fmt_g(y) == ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_1615284655.txt"))
     y, ms, st = sm.tjds_compute(coo, m, n, iters=1025)
     assert len(ms) == 1025 and np.all(ms > 0)
+
+
+def test_config4_full_size_properties(torch):
+    """BASELINE config 4 at its full size: 10 M x 10 M, 32 entries per row (320 M entries, 3.8 GB).
+
+    Size-independent properties only: y(ones) = row sums (independent numpy computation), linearity, agreement of the
+    two tile kernels, run-to-run bit equality, and the oracle on the first 20 000 rows."""
+    M = 10_000_000
+    row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_UNIFORM, 2024, M, M, param=32)
+    assert len(col_ind) == 320_000_000
+    A = sm.CsrMatrix(M, M, row_ptr, col_ind, val)
+    assert A.get_kernel()[0] == sm.CSR_KERNEL_STREAM
+    ones = torch.ones(M, dtype=torch.float64, device="cuda")
+    y1, y2, ya, yb, yab = (torch.empty(M, dtype=torch.float64, device="cuda") for _ in range(5))
+    A.spmv(ones, y1)
+    A.spmv(ones, y2)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+    host = val.reshape(M, 32).sum(axis=1)
+    scale = np.abs(val).reshape(M, 32).sum(axis=1)
+    assert np.all(np.abs(y1.cpu().numpy() - host) <= TOL * scale)
+    rng = np.random.default_rng(11)
+    xa, xb = dev(torch, rng.random(M)), dev(torch, rng.random(M))
+    A.spmv(xa, ya)
+    A.spmv(xb, yb)
+    A.spmv(xa + xb, yab)
+    torch.cuda.synchronize()
+    sc = torch.from_numpy(scale).cuda() * 2
+    assert bool(((yab - (ya + yb)).abs() <= TOL * sc).all())
+    A.set_kernel(sm.CSR_KERNEL_STREAM_CARRY, 0)
+    A.spmv(xa, y2)
+    torch.cuda.synchronize()
+    assert bool(((ya - y2).abs() <= TOL * sc).all())
+    k = 20_000
+    ref = ob.csr_spmv(row_ptr[:k + 1].copy(), col_ind[:row_ptr[k]], val[:row_ptr[k]], xa.cpu().numpy())
+    assert np.array_equal(ya.cpu().numpy()[:k], ref)        # 32 entries per row: one lane, serial order, same bits
+    A.close()
