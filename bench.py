@@ -452,6 +452,11 @@ def main():
                              csr_agrees_with_cpu=bool(np.all(np.abs(y_c - y_cpu) <= TOL * sc)),
                              tjds_agrees_with_cpu=bool(np.all(np.abs(y_t - yt_cpu) <= TOL * sc)),
                              csr_rows_bit_identical=round(float((y_c == y_cpu).mean()), 4))
+                # the only numbers the reference publishes: average times in its committed reports (BASELINE.md,
+                # hardware not stated) -- output-test/smvp-toolbox_report_{CSR,TJDS}_*.txt
+                published = {"memplus.mtx": (0.387638, 0.549908), "pwt.mtx": (0.569281, 1.1823)}[name]
+                e["reference_report_csr_avg_ms"], e["reference_report_tjds_avg_ms"] = published
+                e["csr_vs_reference_report"] = round(published[0] / st_c.time_avg, 1)
                 samples[name] = e
             except Exception as ex:
                 samples[name] = {"error": str(ex)}
