@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0, help="0 = sized for about 15 s")
     ap.add_argument("--no-allgather", action="store_true", help="N > 1: time the local products only")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the same matrix cut into N row blocks (default); weak = N times the matrix")
     return ap.parse_args()
 
 
@@ -132,7 +134,8 @@ def build_block(sm, sharding, workload, args, rank, world):
     if workload == "memplus_tiled":
         tc, m, n, coo = sm.mm_read_coo(golden_file("sample-data", "memplus.mtx"))
         rp, ci, v = sm.csr_from_coo(coo, m)
-        copies = args.copies - args.copies % world if args.copies >= world else world
+        total = args.copies * (world if getattr(args, "scaling", "strong") == "weak" else 1)
+        copies = total - total % world if total >= world else world
         c0, c1 = copies * rank // world, copies * (rank + 1) // world
         row_ptr, col_ind, val = sharding.tile_block_diagonal(rp, ci, v, n, c0, c1)
         blk = dict(rows_total=m * copies, cols_total=n * copies, r0=m * c0, r1=m * c1,
@@ -142,11 +145,11 @@ def build_block(sm, sharding, workload, args, rank, world):
     else:
         if workload == "memplus_shaped":
             kind, seed, param = sm.SYNTH_MEMPLUS_SHAPED, 12345, 0
-            rows_total = cols_total = 1 << args.rows_log2
-            name = "memplus_shaped random model (SURVEY 8(d)) rows=2^%d seed=%d" % (args.rows_log2, seed)
+            rows_total = cols_total = (1 << args.rows_log2) * (world if getattr(args, "scaling", "strong") == "weak" else 1)
+            name = "memplus_shaped random model (SURVEY 8(d)) rows=%d seed=%d" % (rows_total, seed)
         else:
             kind, seed, param = sm.SYNTH_UNIFORM, 2024, 32
-            rows_total = cols_total = args.rows
+            rows_total = cols_total = args.rows * (world if getattr(args, "scaling", "strong") == "weak" else 1)
             name = "uniform 32 entries/row rows=%d seed=%d" % (rows_total, seed)
         bounds = sharding.equal_row_bounds(rows_total, world)
         r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
@@ -490,7 +493,7 @@ def main():
             "metric": "fp64 %s SpMV GFLOP/s (2*nnz flop per product; achieved HBM GB/s in roofline)" % args.format.upper(),
             "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(res["wall_per_step"] * 1e3, 5), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": blk["name"] + ", %s, x=%s" % (args.format.upper(), args.x) +
                        (", %d row blocks + %s all-gather of y" % (world, "RCCL" if backend == "nccl" else backend)
                         if world > 1 and not args.no_allgather else ""),
