@@ -838,3 +838,17 @@ def test_config4_full_size_properties(torch):
     ref = ob.csr_spmv(row_ptr[:k + 1].copy(), col_ind[:row_ptr[k]], val[:row_ptr[k]], xa.cpu().numpy())
     assert np.array_equal(ya.cpu().numpy()[:k], ref)        # 32 entries per row: one lane, serial order, same bits
     A.close()
+
+
+@pytest.mark.parametrize("name", SAMPLES)
+def test_gpu_y_against_committed_golden_vectors(torch, name):
+    """tests/golden/arrays/*.npz: full-precision y of the serial loop (oracle, pinned against the reference's reports)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "arrays", name.replace(".mtx", ".npz")))
+    m, n, coo = load(name)
+    y, _, _ = sm.csr_compute(coo, m, n, iters=2)
+    lens = np.diff(g["row_ptr"])
+    assert np.array_equal(y[lens <= 32], g["y_csr"][lens <= 32])          # one lane, serial order: identical bits
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    assert_close(y, g["y_csr"], row_scale(row_ptr, col_ind, val, np.ones(n)), exact=name in EXACT)
+    yq, _, _ = sm.tjds_compute(coo, m, n, iters=1, ref_quirks=True)
+    assert_close(yq, g["y_tjds_refquirks"], row_scale(row_ptr, col_ind, val, np.ones(n)), exact=name in EXACT)
