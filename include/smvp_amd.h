@@ -177,9 +177,10 @@ int smvp_tjds_create(smvp_tjds_t **out, int device, int rows, int cols, int nnz,
  * kept inside the handle.  Call again whenever x changes. */
 int smvp_tjds_set_x(smvp_tjds_t *h, const double *d_x, void *stream);
 /* The timed product, main-cli.c:1013-1020, in its corrected form
- * y[row_ind[j]] += val[j] * x_perm[j - start_pos[d]].  d_y must be zero on
- * entry (the reference zeroes it outside the timed window, main-cli.c:1008);
- * smvp_tjds_zero_y does that on the same stream. */
+ * y[row_ind[j]] += val[j] * x_perm[j - start_pos[d]].  In the default two-phase mode d_y is
+ * overwritten; in ATOMIC mode (and ref-quirks mode) d_y must be zero on entry -- the reference
+ * zeroes it outside its timed window, main-cli.c:1008 -- and smvp_tjds_zero_y does that on the
+ * same stream (it is a no-op when the mode does not need it, so it is always safe to call). */
 int smvp_tjds_zero_y(smvp_tjds_t *h, double *d_y, void *stream);
 int smvp_tjds_spmv(smvp_tjds_t *h, double *d_y, void *stream);
 /* How the scatter is carried out.  TWO_PHASE (default): products stored once per entry, then summed per row
@@ -190,7 +191,7 @@ enum { SMVP_TJDS_MODE_AUTO = 0, SMVP_TJDS_MODE_ATOMIC = 1, SMVP_TJDS_MODE_TWO_PH
 int smvp_tjds_set_mode(smvp_tjds_t *h, int mode);
 /* Reference-defect emulation for parity with the committed TJDS reports
  * (diagonal count from original column 0, missing terminator, operand indexed
- * by row: main-cli.c:865,951-966,1018).  Host-side edit of the plan; same kernel. */
+ * by row: main-cli.c:865,951-966,1018).  A host-side edit of the launch plan of the atomic kernel. */
 int smvp_tjds_set_ref_quirks(smvp_tjds_t *h, int enable, int ref_num_tjdiag, int last_diag_single);
 int smvp_tjds_describe(const smvp_tjds_t *h, char *kernel_name, size_t cap, double *alg_bytes);
 void smvp_tjds_destroy(smvp_tjds_t *h);
