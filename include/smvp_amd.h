@@ -187,8 +187,14 @@ int smvp_tjds_spmv(smvp_tjds_t *h, double *d_y, void *stream);
  * through a row-inverted index built at create time -- no atomics, bit-reproducible, y needs no zeroing
  * (smvp_tjds_zero_y becomes a no-op).  ATOMIC: one pass, fp64 atomic adds into a zeroed y (order varies from
  * run to run).  Ref-quirks mode always runs the atomic form. */
-enum { SMVP_TJDS_MODE_AUTO = 0, SMVP_TJDS_MODE_ATOMIC = 1, SMVP_TJDS_MODE_TWO_PHASE = 2 };
+enum {
+    SMVP_TJDS_MODE_AUTO = 0,               /* = ROW_GATHER */
+    SMVP_TJDS_MODE_ATOMIC = 1,
+    SMVP_TJDS_MODE_TWO_PHASE = 2,
+    SMVP_TJDS_MODE_ROW_GATHER = 3 /* one kernel, no atomics: the entries regrouped by row at create time */
+};
 int smvp_tjds_set_mode(smvp_tjds_t *h, int mode);
+int smvp_tjds_set_tile(smvp_tjds_t *h, int entries_per_tile); /* ROW_GATHER*: 256, 1024 or 2048 entries per workgroup */
 /* Reference-defect emulation for parity with the committed TJDS reports
  * (diagonal count from original column 0, missing terminator, operand indexed
  * by row: main-cli.c:865,951-966,1018).  A host-side edit of the launch plan of the atomic kernel. */
@@ -228,9 +234,25 @@ typedef struct smvp_run_opts {
     int iterate;        /* 1: power iteration, x_{k+1} = A x_k for `iters` steps -- the product the assignment asked
                            for (comment at main-cli.c:401); square matrices; y = the last iterate; each step timed */
     int normalize;      /* with iterate: divide every iterate by its largest magnitude (keeps 1000 steps finite) */
+    int tjds_mode;      /* SMVP_TJDS_MODE_* for smvp_tjds_compute (AUTO = ROW_GATHER) */
+    int timing;         /* SMVP_TIMING_*: how each product is timed */
     const double *x;    /* host operand, NULL = all ones (main-cli.c:368-369) */
 } smvp_run_opts_t;
 void smvp_run_opts_default(smvp_run_opts_t *o);
+
+/* How the per-product window of main-cli.c:408-419 is taken.  EVENTS: a hipEvent pair around each product's
+ * launches.  DEVICE: the kernel times itself -- every wave notes the device's constant-rate wall clock when it
+ * starts and when its last store has been acknowledged; the product's time is max(last) - min(first) -- and the
+ * products are replayed from a hipGraph.  AUTO picks DEVICE for launches of up to 4096 workgroups of the tile
+ * kernels (where an event pair would measure mostly itself: the reference's own sample matrices), else EVENTS. */
+enum { SMVP_TIMING_AUTO = 0, SMVP_TIMING_EVENTS = 1, SMVP_TIMING_DEVICE = 2 };
+typedef struct smvp_run_info {
+    int timing;            /* SMVP_TIMING_EVENTS or SMVP_TIMING_DEVICE: what the last smvp_*_compute on this thread used */
+    int graph_replays;     /* hipGraph launches it took (0 = plain launches) */
+    double wall_ms;        /* host wall time of the whole timed loop, launches, timing and waits included */
+    double device_clock_khz; /* DEVICE: rate of the clock the times were taken with */
+} smvp_run_info_t;
+int smvp_last_run_info(smvp_run_info_t *out);
 
 /* Replaces  double *smvp_csr_compute(MMRawData*, int rows, int nnz, int iters,
  *                                    struct _time_data_*)      main-cli.c:325-469

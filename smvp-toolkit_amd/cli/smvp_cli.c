@@ -20,6 +20,7 @@
  *   - libpopt is not used (absent from the image): getopt_long("+...") gives the
  *     same POSIX ordering rule.
  * Additive flags: --device N, --gpus N, --iterate, --normalize, --ref-quirks, --device-convert, --csr-kernel auto|vector|stream|stream-carry,
+ * --tjds-mode auto|row-gather|two-phase|atomic, --timing auto|events|device,
  * --quiet-arrays is implied (the reference's SMVP_CSR_DEBUG array dumps,
  * main-cli.c:374-394, are not printed).
  */
@@ -42,7 +43,8 @@
 #define RESET "\x1b[0m"
 
 enum { ALG_NONE = 0, ALG_CSR = 1 << 1, ALG_TJDS = 1 << 2, ALG_CISR = 1 << 3, ALG_ALL = 256 };
-enum { OPT_DEVICE = 1000, OPT_QUIRKS, OPT_KERNEL, OPT_USAGE, OPT_DEVCONV, OPT_GPUS, OPT_ITERATE, OPT_NORMALIZE };
+enum { OPT_DEVICE = 1000, OPT_QUIRKS, OPT_KERNEL, OPT_USAGE, OPT_DEVCONV, OPT_GPUS, OPT_ITERATE, OPT_NORMALIZE, OPT_TIMING,
+       OPT_TJDS_MODE };
 
 static void usage(FILE *to, const char *prog)
 {
@@ -50,6 +52,7 @@ static void usage(FILE *to, const char *prog)
             "Usage: %s [-acgt?] [-a|--all-algs] [-c|--csr] [-g|--cisr-gen] [-t|--tjds]\n"
             "        [-n|--number=1000] [-s|--slots=16] [-d|--dir=./] [--device=0] [--gpus=1]\n"
             "        [--ref-quirks] [--iterate] [--normalize] [--device-convert] [--csr-kernel=auto|vector|stream|stream-carry]\n"
+            "        [--tjds-mode=auto|row-gather|two-phase|atomic] [--timing=auto|events|device]\n"
             "        [-?|--help] [--usage]\n"
             "        [OPTIONS] <file>\n",
             prog);
@@ -72,6 +75,8 @@ static void help(const char *prog)
     puts("      --ref-quirks         Reproduce the reference v0.6.4 TJDS output, defects included.");
     puts("      --device-convert     Build CSR / TJDS from the loaded entries on the GPU instead of the host.");
     puts("      --csr-kernel=auto    CSR kernel family: auto, vector, stream, stream-carry.");
+    puts("      --tjds-mode=auto     TJDS product: auto (= row-gather, one kernel), two-phase, atomic.");
+    puts("      --timing=auto        Per-product window: events (hipEvent pair), device (the kernel times itself), auto.");
     puts("\nHelp options:");
     puts("  -?, --help               Show this help message");
     puts("      --usage              Display brief usage message");
@@ -129,6 +134,15 @@ static void print_rates(const char *alg, int rows, int cols, int nnz, int diags,
     if (t->time_avg > 0.0)
         printf(CYAN "[DATA]\t%s average per product: " RESET "%g ms, %.3f GFLOP/s, %.3f GB/s algorithmic\n", alg,
                t->time_avg, flops / t->time_avg * 1e-6, bytes / t->time_avg * 1e-6);
+    /* how the window of main-cli.c:408-419 was taken, and what the whole loop cost the host */
+    smvp_run_info_t info;
+    if (smvp_last_run_info(&info) == SMVP_OK && info.wall_ms > 0.0)
+        printf(CYAN "[DATA]\t%s timing: " RESET "%s; whole loop %g ms of host wall time\n", alg,
+               info.timing == SMVP_TIMING_DEVICE
+                   ? (info.graph_replays ? "per product on the device (wall-clock stamps in the kernel), products replayed from a hipGraph"
+                                         : "per product on the device (wall-clock stamps in the kernel)")
+                   : "hipEvent pair around each product",
+               info.wall_ms);
 }
 
 int main(int argc, char *argv[])
@@ -142,10 +156,12 @@ int main(int argc, char *argv[])
         {"ref-quirks", no_argument, NULL, OPT_QUIRKS}, {"csr-kernel", required_argument, NULL, OPT_KERNEL},
         {"device-convert", no_argument, NULL, OPT_DEVCONV}, {"gpus", required_argument, NULL, OPT_GPUS},
         {"iterate", no_argument, NULL, OPT_ITERATE}, {"normalize", no_argument, NULL, OPT_NORMALIZE},
+        {"timing", required_argument, NULL, OPT_TIMING}, {"tjds-mode", required_argument, NULL, OPT_TJDS_MODE},
         {NULL, 0, NULL, 0}};
     const char *prog = "smvp-toolkit-cli";
     int alg_mode = ALG_NONE, calc_iter = 1000, cisr_slots = 16, device = 0, quirks = 0;
     int csr_kernel = SMVP_CSR_KERNEL_AUTO, device_convert = 0, ngpus = 1, iterate = 0, normalize = 0;
+    int timing = SMVP_TIMING_AUTO, tjds_mode = SMVP_TJDS_MODE_AUTO;
     const char *report_dir = "";
 
     if (argc < 2) { /* main-cli.c:1267-1271 */
@@ -227,6 +243,28 @@ int main(int argc, char *argv[])
                 csr_kernel = SMVP_CSR_KERNEL_STREAM_CARRY;
             else
                 die("Unknown CSR kernel family (use auto, vector, stream or stream-carry).");
+            break;
+        case OPT_TIMING:
+            if (strcmp(optarg, "auto") == 0)
+                timing = SMVP_TIMING_AUTO;
+            else if (strcmp(optarg, "events") == 0)
+                timing = SMVP_TIMING_EVENTS;
+            else if (strcmp(optarg, "device") == 0)
+                timing = SMVP_TIMING_DEVICE;
+            else
+                die("Unknown timing method (use auto, events or device).");
+            break;
+        case OPT_TJDS_MODE:
+            if (strcmp(optarg, "auto") == 0)
+                tjds_mode = SMVP_TJDS_MODE_AUTO;
+            else if (strcmp(optarg, "row-gather") == 0)
+                tjds_mode = SMVP_TJDS_MODE_ROW_GATHER;
+            else if (strcmp(optarg, "two-phase") == 0)
+                tjds_mode = SMVP_TJDS_MODE_TWO_PHASE;
+            else if (strcmp(optarg, "atomic") == 0)
+                tjds_mode = SMVP_TJDS_MODE_ATOMIC;
+            else
+                die("Unknown TJDS product form (use auto, row-gather, two-phase or atomic).");
             break;
         case OPT_USAGE:
             usage(stdout, prog);
@@ -324,6 +362,8 @@ int main(int argc, char *argv[])
     opts.ngpus = ngpus;
     opts.iterate = iterate;
     opts.normalize = normalize;
+    opts.timing = timing;
+    opts.tjds_mode = tjds_mode;
     smvp_time_stats_t st;
     char path[4096];
 

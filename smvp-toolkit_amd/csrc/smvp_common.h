@@ -15,4 +15,10 @@ void clear_error();
 struct ihipStream_t;
 namespace smvp {
 int build_row_inverse(const int *d_row_ind, int nnz, int rows, int *d_inv_ptr, int *d_inv_pos, ihipStream_t *stream);
+int build_row_gather_plan(const int *d_row_ind, const int *d_start_pos, int num_diag, int nnz, int rows,
+                          int *d_seg_ptr, int *d_pos, int *d_kcol, ihipStream_t *stream);
+int sort_tile_windows(const int *d_pos, int nnz, int tile, const int *d_start_pos, int num_diag, int slot_bits,
+                      int *d_pos_sorted, int *d_meta, ihipStream_t *stream);
+int build_tile_overflow(const int *d_pos, const int *d_ovf_ptr, int total, int ntiles, int tile, int nnz,
+                        const int *d_start_pos, int num_diag, int *d_ovf_pos, int *d_ovf_k, ihipStream_t *stream);
 }

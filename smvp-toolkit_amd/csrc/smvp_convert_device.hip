@@ -271,6 +271,158 @@ int build_row_inverse(const int *d_row_ind, int nnz, int rows, int *d_inv_ptr, i
 
 }  // namespace smvp
 
+namespace {
+
+// jagged diagonal d of TJDS position p: start_pos[d] <= p < start_pos[d + 1]; permuted column k = p - start_pos[d]
+__global__ __launch_bounds__(256) void positions_to_columns(const int *__restrict__ pos, int nnz,
+                                                            const int *__restrict__ start_pos, int num_diag,
+                                                            int *__restrict__ kcol)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nnz)
+        return;
+    const int p = pos[e];
+    int lo = 0, hi = num_diag - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (start_pos[mid] <= p)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    kcol[e] = p - start_pos[lo];
+}
+
+}  // namespace
+
+namespace {
+
+__global__ __launch_bounds__(256) void window_keys(const int *__restrict__ pos, int nnz, int tile, u64 *__restrict__ key,
+                                                   unsigned *__restrict__ slot)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nnz)
+        return;
+    key[e] = ((u64)(unsigned)(e / tile) << 32) | (unsigned)pos[e];
+    slot[e] = (unsigned)(e % tile);
+}
+
+__device__ __forceinline__ int diagonal_of(const int *__restrict__ start_pos, int num_diag, int p)
+{
+    int lo = 0, hi = num_diag - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (start_pos[mid] <= p)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void window_streams(const u64 *__restrict__ key, const unsigned *__restrict__ slot, int nnz,
+                                                      const int *__restrict__ start_pos, int num_diag, int slot_bits,
+                                                      int *__restrict__ pos_sorted, int *__restrict__ meta)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nnz)
+        return;
+    const int p = (int)(unsigned)(key[e] & 0xffffffffu);
+    pos_sorted[e] = p;
+    meta[e] = (int)(slot[e] | ((unsigned)diagonal_of(start_pos, num_diag, p) << slot_bits));
+}
+
+__global__ __launch_bounds__(256) void overflow_entries(const int *__restrict__ pos, const int *__restrict__ ovf_ptr,
+                                                        int ntiles, int tile, int nnz, const int *__restrict__ start_pos,
+                                                        int num_diag, int *__restrict__ ovf_pos, int *__restrict__ ovf_k)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ovf_ptr[ntiles])
+        return;
+    int lo = 0, hi = ntiles - 1;  // last tile b with ovf_ptr[b] <= i (tiles without overflow share a start: take the last)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (ovf_ptr[mid] <= i)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const long long e = (long long)(lo + 1) * tile;  // a tile with overflow entries is a full one
+    const int p = pos[e + (i - ovf_ptr[lo])];
+    ovf_pos[i] = p;
+    ovf_k[i] = p - start_pos[diagonal_of(start_pos, num_diag, p)];
+}
+
+}  // namespace
+
+namespace smvp {
+
+// kFlavorTjdsS: the row-major stream `d_pos` cut into windows of `tile` entries, every window sorted by TJDS position;
+// meta = the entry's place in its window before sorting (its LDS slot) | its jagged diagonal << slot_bits.
+int sort_tile_windows(const int *d_pos, int nnz, int tile, const int *d_start_pos, int num_diag, int slot_bits,
+                      int *d_pos_sorted, int *d_meta, hipStream_t st)
+{
+    if (nnz <= 0)
+        return SMVP_OK;
+    if (tile > (1 << slot_bits) || ((long long)(num_diag - 1) >> (32 - slot_bits)) != 0)
+        return smvp::fail(SMVP_ERR_UNSUPPORTED, "sort_tile_windows: tile %d / %d diagonals do not fit the packed word", tile, num_diag);
+    Scratch sc;
+    u64 *k0, *k1;
+    unsigned *s0, *s1;
+    HIP_TRY(sc.get(&k0, (size_t)nnz));
+    HIP_TRY(sc.get(&k1, (size_t)nnz));
+    HIP_TRY(sc.get(&s0, (size_t)nnz));
+    HIP_TRY(sc.get(&s1, (size_t)nnz));
+    hipLaunchKernelGGL(window_keys, dim3(blocks_for(nnz)), dim3(256), 0, st, d_pos, nnz, tile, k0, s0);
+    HIP_TRY(hipGetLastError());
+    const unsigned bits = 32u + (unsigned)bits_for((nnz + tile - 1) / tile + 1);
+    size_t tmp_bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, s0, s1, (size_t)nnz, 0u, bits, st));
+    char *tmp;
+    HIP_TRY(sc.get(&tmp, tmp_bytes));
+    HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, s0, s1, (size_t)nnz, 0u, bits, st));
+    hipLaunchKernelGGL(window_streams, dim3(blocks_for(nnz)), dim3(256), 0, st, k1, s1, nnz, d_start_pos, num_diag, slot_bits,
+                       d_pos_sorted, d_meta);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    return SMVP_OK;
+}
+
+// the entries [e_b, tile_next_b) every tile b needs from beyond its end, kept in row order: ovf_ptr[ntiles + 1] (device)
+int build_tile_overflow(const int *d_pos, const int *d_ovf_ptr, int total, int ntiles, int tile, int nnz,
+                        const int *d_start_pos, int num_diag, int *d_ovf_pos, int *d_ovf_k, hipStream_t st)
+{
+    if (total <= 0)
+        return SMVP_OK;
+    hipLaunchKernelGGL(overflow_entries, dim3(blocks_for(total)), dim3(256), 0, st, d_pos, d_ovf_ptr, ntiles, tile, nnz,
+                       d_start_pos, num_diag, d_ovf_pos, d_ovf_k);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    return SMVP_OK;
+}
+
+}  // namespace smvp
+
+namespace smvp {
+
+// Row-gather plan of a TJDS matrix (the one-kernel TJDS product, csr_stream_owner<., kFlavorTjds*>): the entries
+// regrouped by row -- seg_ptr[rows + 1] bounds, pos[nnz] TJDS positions ascending inside a row -- and, if asked for,
+// each stream entry's permuted column kcol.  val / row_ind / start_pos / perm themselves are only read.
+int build_row_gather_plan(const int *d_row_ind, const int *d_start_pos, int num_diag, int nnz, int rows,
+                          int *d_seg_ptr, int *d_pos, int *d_kcol, hipStream_t st)
+{
+    if (int rc = build_row_inverse(d_row_ind, nnz, rows, d_seg_ptr, d_pos, st))
+        return rc;
+    if (nnz > 0 && d_kcol) {
+        hipLaunchKernelGGL(positions_to_columns, dim3(blocks_for(nnz)), dim3(256), 0, st, d_pos, nnz, d_start_pos, num_diag, d_kcol);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return SMVP_OK;
+}
+
+}  // namespace smvp
+
 extern "C" int smvp_csr_from_coo_device(const smvp_coo_t *d_coo, int rows, int cols, int nnz,
                                         int *d_row_ptr, int *d_col_ind, double *d_val, void *stream)
 {

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -112,7 +113,15 @@ struct smvp_csr {
     bool own_row_ptr = false, own_col_ind = false, own_val = false;
     std::vector<int> h_row_ptr;  // kept for re-planning
 
-    bool unit_val = false;  // every value is 1 and d_val is not read (second phase of the two-phase TJDS product)
+    // what an entry of the stream is (smvp_kernels.h kFlavor*): plain CSR, the unit-value form (second phase of the
+    // two-phase TJDS product), or a TJDS matrix regrouped by rows (the one-kernel TJDS product); the TJDS flavours
+    // borrow these arrays from their smvp_tjds owner
+    int flavor = smvp::kFlavorCsr;
+    const int *d_pos = nullptr;       // TjdsK/D: what the kernel reads; TjdsS: the row-major stream the tiles are sorted from
+    const int *d_start_pos = nullptr;
+    int num_diag = 0;
+    // TjdsS: per-tile TJDS-ordered streams and the tiles' overflow entries, owned, rebuilt with the tile plan
+    int *d_pos_sorted = nullptr, *d_meta = nullptr, *d_ovf_ptr = nullptr, *d_ovf_pos = nullptr, *d_ovf_k = nullptr;
     int kernel = SMVP_CSR_KERNEL_AUTO;  // resolved: VECTOR or STREAM
     int lanes_per_row = 64;             // VECTOR
     int vpt = 4;                        // STREAM: entries per thread (tile = 256 * vpt)
@@ -136,6 +145,10 @@ void free_stream_plan(smvp_csr *h)
         (void)hipFree(h->d_carry);
     if (h->d_tile_next)
         (void)hipFree(h->d_tile_next);
+    for (void *p : {(void *)h->d_pos_sorted, (void *)h->d_meta, (void *)h->d_ovf_ptr, (void *)h->d_ovf_pos, (void *)h->d_ovf_k})
+        if (p)
+            (void)hipFree(p);
+    h->d_pos_sorted = h->d_meta = h->d_ovf_ptr = h->d_ovf_pos = h->d_ovf_k = nullptr;
     h->d_tile_row = h->d_carry_row = h->d_tile_next = nullptr;
     h->d_carry = nullptr;
     h->ntiles = 0;
@@ -176,6 +189,30 @@ int build_stream_plan(smvp_csr *h)
         HIP_TRY(hipMemset(h->d_carry, 0, std::max(ntiles, 1) * sizeof(double)));
     }
     h->ntiles = ntiles;
+    if (h->flavor == smvp::kFlavorTjdsS) {
+        // every tile's entries in TJDS order + what each tile reads past its end, in row order
+        std::vector<int> ovf_ptr((size_t)ntiles + 1, 0);
+        for (int b = 0; b < ntiles; ++b) {
+            const long long e = std::min((long long)(b + 1) * tile, nnz);
+            const bool owns = tile_row[(size_t)b] != tile_row[(size_t)b + 1];
+            ovf_ptr[(size_t)b + 1] = ovf_ptr[(size_t)b] + (owns ? (int)(tile_next[(size_t)b] - e) : 0);
+        }
+        const int total = ovf_ptr[(size_t)ntiles];
+        if (int rc = upload(&h->d_ovf_ptr, ovf_ptr))
+            return rc;
+        const size_t n = (size_t)std::max(h->nnz, 4), m = (size_t)std::max(total, 4);
+        if (hipMalloc((void **)&h->d_pos_sorted, n * sizeof(int)) != hipSuccess ||
+            hipMalloc((void **)&h->d_meta, n * sizeof(int)) != hipSuccess ||
+            hipMalloc((void **)&h->d_ovf_pos, m * sizeof(int)) != hipSuccess ||
+            hipMalloc((void **)&h->d_ovf_k, m * sizeof(int)) != hipSuccess)
+            return smvp::fail(SMVP_ERR_ALLOC, "cannot allocate the tile-ordered TJDS streams");
+        if (int rc = smvp::sort_tile_windows(h->d_pos, h->nnz, tile, h->d_start_pos, h->num_diag, smvp::kSlotBits,
+                                             h->d_pos_sorted, h->d_meta, nullptr))
+            return rc;
+        if (int rc = smvp::build_tile_overflow(h->d_pos, h->d_ovf_ptr, total, ntiles, tile, h->nnz, h->d_start_pos,
+                                               h->num_diag, h->d_ovf_pos, h->d_ovf_k, nullptr))
+            return rc;
+    }
     return SMVP_OK;
 }
 
@@ -195,29 +232,48 @@ int pow2_at_least(double v)
 // 0.98 / 0.86 / 0.87 of the tile kernel's rate, and far below it on skewed rows.
 constexpr int kOwnerMaxRow = 16 * 1024;
 
-void choose_csr_kernel(smvp_csr *h, int kernel, int param)
+// false: `param` is no tile size the resolved kernel is compiled for (nothing is changed then)
+bool choose_csr_kernel(smvp_csr *h, int kernel, int param)
 {
     const double mean = h->rows > 0 ? (double)h->nnz / h->rows : 0.0;
     if (kernel == SMVP_CSR_KERNEL_AUTO)
         kernel = h->max_row_len > kOwnerMaxRow ? SMVP_CSR_KERNEL_STREAM_CARRY : SMVP_CSR_KERNEL_STREAM;
+    if (kernel == SMVP_CSR_KERNEL_STREAM && param != 0 && param != 256 && param != 1024 && param != 2048)
+        return false;
+    if (kernel == SMVP_CSR_KERNEL_STREAM_CARRY && param != 0 && param != 1024 && param != 2048)
+        return false;
     h->kernel = kernel;
     if (kernel == SMVP_CSR_KERNEL_VECTOR) {
         h->lanes_per_row = param > 0 ? param : pow2_at_least(mean);
     } else {
         int tile = param > 0 ? param : 0;
-        if (tile == 0)  // 1024 measured 1-4 % ahead of 2048 on memplus x944 and pwt x459; 256-entry tiles when
+        if (tile == 0) {  // 1024 measured 1-4 % ahead of 2048 on memplus x944 and pwt x459; 256-entry tiles when
             tile = (kernel == SMVP_CSR_KERNEL_STREAM && h->nnz < 512 * 1024) ? 256 : 1024;  // 1024 would leave CUs idle
+            if (h->flavor == smvp::kFlavorTjdsS && tile == 1024)
+                tile = 2048;  // more entries per val line inside a tile: 0.592 vs 0.62 ms on memplus x944
+        }
         h->vpt = tile / smvp::kStreamBlock;
     }
+    return true;
 }
 
 }  // namespace
 
+// what a TJDS flavour borrows from its smvp_tjds owner (set before the tile plan is built)
+struct TjdsSource {
+    const int *pos = nullptr;
+    const int *start_pos = nullptr;
+    int num_diag = 0;
+};
+
 static int csr_create_impl(smvp_csr_t **out, int device, int rows, int cols, int nnz,
                            const int *row_ptr, const int *col_ind, const double *val,
-                           int mem_kind, const int *host_row_ptr, bool unit_val)
+                           int mem_kind, const int *host_row_ptr, int flavor, const TjdsSource *src = nullptr)
 {
-    if (!out || rows < 0 || cols < 0 || nnz < 0 || !row_ptr || (nnz > 0 && (!col_ind || (!val && !unit_val))))
+    const bool unit_val = flavor == smvp::kFlavorUnit;
+    const bool plain = flavor == smvp::kFlavorCsr;
+    if (!out || rows < 0 || cols < 0 || nnz < 0 || !row_ptr ||
+        (nnz > 0 && ((!col_ind && flavor != smvp::kFlavorTjdsS) || (!val && !unit_val))))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: bad argument");
     if (mem_kind != SMVP_MEM_HOST && mem_kind != SMVP_MEM_DEVICE)
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: bad mem_kind");
@@ -225,11 +281,15 @@ static int csr_create_impl(smvp_csr_t **out, int device, int rows, int cols, int
         return smvp::fail(SMVP_ERR_UNSUPPORTED, "smvp_csr_create: %d entries: shard blocks this large by rows", nnz);
     if (int rc = usable_device(device))
         return rc;
-    HIP_TRY(hipSetDevice(device));
+    DeviceScope on(device);
 
     smvp_csr *h = new smvp_csr;
     h->device = device;
-    h->unit_val = unit_val;
+    h->flavor = flavor;
+    if (src) {
+        h->d_pos = src->pos, h->d_start_pos = src->start_pos;
+        h->num_diag = src->num_diag;
+    }
     h->rows = rows, h->cols = cols, h->nnz = nnz;
     h->h_row_ptr.resize((size_t)rows + 1);
     int rc = SMVP_OK;
@@ -257,19 +317,19 @@ static int csr_create_impl(smvp_csr_t **out, int device, int rows, int cols, int
             }
     }
     if (rc == SMVP_OK && mem_kind == SMVP_MEM_DEVICE &&
-        (((uintptr_t)col_ind | (unit_val ? 0 : (uintptr_t)val)) & 15u) != 0)
+        (((uintptr_t)col_ind | (plain ? (uintptr_t)val : 0)) & 15u) != 0)
         rc = smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: adopted device arrays must be 16-byte aligned");
-    if (rc == SMVP_OK && mem_kind == SMVP_MEM_DEVICE)
+    if (rc == SMVP_OK && mem_kind == SMVP_MEM_DEVICE && col_ind)
         rc = check_device_indices(col_ind, nnz, cols, "smvp_csr_create: col_ind");
     if (rc == SMVP_OK)
         rc = to_device(&h->d_row_ptr, row_ptr, (size_t)rows + 1, mem_kind, &h->own_row_ptr);
-    if (rc == SMVP_OK)
+    if (rc == SMVP_OK && col_ind)
         rc = to_device(&h->d_col_ind, col_ind, (size_t)nnz, mem_kind, &h->own_col_ind);
     if (rc == SMVP_OK && !unit_val)
         rc = to_device(&h->d_val, val, (size_t)nnz, mem_kind, &h->own_val);
     if (rc == SMVP_OK) {
-        // the unit-value form exists for the owner-completes kernel only
-        choose_csr_kernel(h, unit_val ? SMVP_CSR_KERNEL_STREAM : SMVP_CSR_KERNEL_AUTO, 0);
+        // every flavour but plain CSR exists for the owner-completes kernel only
+        choose_csr_kernel(h, plain ? SMVP_CSR_KERNEL_AUTO : SMVP_CSR_KERNEL_STREAM, 0);
         if (h->kernel != SMVP_CSR_KERNEL_VECTOR)
             rc = build_stream_plan(h);
     }
@@ -285,26 +345,24 @@ extern "C" int smvp_csr_create(smvp_csr_t **out, int device, int rows, int cols,
                                const int *row_ptr, const int *col_ind, const double *val,
                                int mem_kind, const int *host_row_ptr)
 {
-    return csr_create_impl(out, device, rows, cols, nnz, row_ptr, col_ind, val, mem_kind, host_row_ptr, false);
+    return csr_create_impl(out, device, rows, cols, nnz, row_ptr, col_ind, val, mem_kind, host_row_ptr, smvp::kFlavorCsr);
 }
 
 extern "C" int smvp_csr_set_kernel(smvp_csr_t *h, int kernel, int param)
 {
     if (!h)
         return smvp::fail(SMVP_ERR_INVALID, "null handle");
-    if (h->unit_val && kernel != SMVP_CSR_KERNEL_STREAM)
-        return smvp::fail(SMVP_ERR_UNSUPPORTED, "a unit-value matrix runs on the stream kernel only");
+    if (h->flavor != smvp::kFlavorCsr && kernel != SMVP_CSR_KERNEL_STREAM)
+        return smvp::fail(SMVP_ERR_UNSUPPORTED, "this matrix flavour runs on the stream kernel only");
     if (kernel < SMVP_CSR_KERNEL_AUTO || kernel > SMVP_CSR_KERNEL_STREAM_CARRY)
         return smvp::fail(SMVP_ERR_INVALID, "unknown CSR kernel %d", kernel);
     if (kernel == SMVP_CSR_KERNEL_VECTOR && param != 0 &&
         (param < 2 || param > 64 || (param & (param - 1)) != 0))
         return smvp::fail(SMVP_ERR_INVALID, "lanes per row must be a power of two in [2, 64]");
-    if (kernel == SMVP_CSR_KERNEL_STREAM && param != 0 && param != 256 && param != 1024 && param != 2048)
-        return smvp::fail(SMVP_ERR_INVALID, "entries per tile must be 256, 1024 or 2048");
-    if (kernel == SMVP_CSR_KERNEL_STREAM_CARRY && param != 0 && param != 1024 && param != 2048)
-        return smvp::fail(SMVP_ERR_INVALID, "entries per tile must be 1024 or 2048");
-    HIP_TRY(hipSetDevice(h->device));
-    choose_csr_kernel(h, kernel, param);
+    DeviceScope on(h->device);
+    if (!choose_csr_kernel(h, kernel, param))
+        return smvp::fail(SMVP_ERR_INVALID, "entries per tile must be 256 (stream only), 1024 or 2048 for the kernel "
+                                            "this matrix resolves to");
     if (h->kernel != SMVP_CSR_KERNEL_VECTOR)
         return build_stream_plan(h);
     free_stream_plan(h);
@@ -322,7 +380,8 @@ extern "C" int smvp_csr_get_kernel(const smvp_csr_t *h, int *kernel, int *param)
     return SMVP_OK;
 }
 
-extern "C" int smvp_csr_spmv(smvp_csr_t *h, const double *d_x, double *d_y, void *stream)
+// stamps: device-side timing slots of this launch (owner kernel only), or nullptr
+static int csr_spmv_impl(smvp_csr_t *h, const double *d_x, double *d_y, void *stream, unsigned long long *stamps)
 {
     if (!h || (h->rows > 0 && !d_y) || (h->nnz > 0 && !d_x))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_spmv: bad argument");
@@ -333,16 +392,33 @@ extern "C" int smvp_csr_spmv(smvp_csr_t *h, const double *d_x, double *d_y, void
     hipError_t e;
     if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
         e = smvp::launch_csr_vector(h->lanes_per_row, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y, h->rows, st);
-    else if (h->kernel == SMVP_CSR_KERNEL_STREAM)
-        e = smvp::launch_csr_stream_owner(h->vpt, h->unit_val, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y,
-                                          h->d_tile_row, h->d_tile_next, h->rows, h->nnz, h->ntiles, st);
-    else
+    else if (h->kernel == SMVP_CSR_KERNEL_STREAM) {
+        smvp::OwnerLaunch l;
+        l.row_ptr = h->d_row_ptr, l.col_ind = h->d_col_ind, l.val = h->d_val, l.x = d_x, l.y = d_y;
+        l.tile_row = h->d_tile_row, l.tile_next = h->d_tile_next;
+        l.pos = h->d_pos, l.start_pos = h->d_start_pos;
+        if (h->flavor == smvp::kFlavorTjdsS) {
+            l.pos = h->d_pos_sorted, l.col_ind = h->d_meta;
+            l.ovf_ptr = h->d_ovf_ptr, l.ovf_pos = h->d_ovf_pos, l.ovf_k = h->d_ovf_k;
+        }
+        l.stamps = stamps;
+        l.rows = h->rows, l.nnz = h->nnz, l.ntiles = h->ntiles;
+        e = smvp::launch_csr_stream_owner(h->vpt, h->flavor, l, st);
+    } else
         e = smvp::launch_csr_stream(h->vpt, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y, h->d_tile_row,
                                     h->d_carry_row, h->d_carry, h->rows, h->nnz, h->ntiles, st);
     if (e != hipSuccess)
         return smvp::fail(SMVP_ERR_HIP, "CSR launch failed: %s", hipGetErrorString(e));
     return SMVP_OK;
 }
+
+extern "C" int smvp_csr_spmv(smvp_csr_t *h, const double *d_x, double *d_y, void *stream)
+{
+    return csr_spmv_impl(h, d_x, d_y, stream, nullptr);
+}
+
+// the owner kernel of a launch small enough to be timed on the device (see StampTimer)?
+static bool csr_can_stamp(const smvp_csr_t *h) { return h && h->kernel == SMVP_CSR_KERNEL_STREAM && h->d_tile_row; }
 
 extern "C" int smvp_csr_describe(const smvp_csr_t *h, char *kernel_name, size_t cap, double *alg_bytes)
 {
@@ -352,7 +428,7 @@ extern "C" int smvp_csr_describe(const smvp_csr_t *h, char *kernel_name, size_t 
         if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
             snprintf(kernel_name, cap, "csr_vector_rows<%d>", h->lanes_per_row);
         else if (h->kernel == SMVP_CSR_KERNEL_STREAM)
-            snprintf(kernel_name, cap, h->unit_val ? "csr_stream_owner<%d, true>" : "csr_stream_owner<%d, false>", h->vpt);
+            snprintf(kernel_name, cap, "csr_stream_owner<%d, %d>", h->vpt, h->flavor);
         else
             snprintf(kernel_name, cap, "csr_stream_tiles<%d>", h->vpt);
     }
@@ -365,7 +441,7 @@ extern "C" void smvp_csr_destroy(smvp_csr_t *h)
 {
     if (!h)
         return;
-    (void)hipSetDevice(h->device);
+    DeviceScope on(h->device);
     free_stream_plan(h);
     if (h->own_row_ptr && h->d_row_ptr)
         (void)hipFree(h->d_row_ptr);
@@ -392,8 +468,18 @@ struct smvp_tjds {
     double *d_x_perm = nullptr;  // max(rows, cols) doubles
     bool x_set = false;
 
-    // two-phase (atomic-free) product: per-entry products + their sum per row through the row-inverted index
-    int mode = SMVP_TJDS_MODE_TWO_PHASE;
+    int mode = SMVP_TJDS_MODE_ROW_GATHER;
+
+    // one-kernel product (ROW_GATHER): the entries regrouped by row -- segment bounds and TJDS positions, plus the
+    // permuted columns when the 32-bit form is used; `rg` is the owner-kernel plan over that stream (the
+    // tile-ordered form keeps its own sorted copies).  Built on first use of the mode.
+    int *d_rg_ptr = nullptr;      // rows + 1
+    int *d_rg_pos = nullptr;      // nnz, row order
+    int *d_rg_k = nullptr;        // nnz, kFlavorTjdsK only
+    smvp_csr *rg = nullptr;
+
+    // two-phase product (TWO_PHASE): per-entry products + their sum per row through the row-inverted index;
+    // built on first use of the mode
     double *d_prod = nullptr;    // nnz doubles
     int *d_inv_ptr = nullptr;    // rows + 1
     int *d_inv_pos = nullptr;    // nnz: positions j grouped by row_ind[j], ascending inside a row
@@ -451,6 +537,79 @@ int build_tjds_plan(smvp_tjds *h, bool quirks, int ref_num_tjdiag, int last_diag
     return SMVP_OK;
 }
 
+
+void free_row_gather(smvp_tjds *h)
+{
+    smvp_csr_destroy(h->rg);
+    h->rg = nullptr;
+    for (void *p : {(void *)h->d_rg_ptr, (void *)h->d_rg_pos, (void *)h->d_rg_k})
+        if (p)
+            (void)hipFree(p);
+    h->d_rg_ptr = h->d_rg_pos = h->d_rg_k = nullptr;
+}
+
+// How the row-gather stream names an entry's permuted column: tile-ordered streams with packed slot | diagonal words
+// (kFlavorTjdsS) when the diagonals fit 21 bits, else 32-bit permuted columns in row order (kFlavorTjdsK);
+// SMVP_TJDS_INDEX=k32|sorted overrides (development switch).
+int row_gather_index(const smvp_tjds *h)
+{
+    const char *e = getenv("SMVP_TJDS_INDEX");
+    const bool fits_sorted = ((long long)std::max(h->num_diag - 1, 0) >> (32 - smvp::kSlotBits)) == 0;
+    if (e && !strcmp(e, "k32"))
+        return smvp::kFlavorTjdsK;
+    return fits_sorted ? smvp::kFlavorTjdsS : smvp::kFlavorTjdsK;
+}
+
+int ensure_row_gather(smvp_tjds *h)
+{
+    if (h->rg)
+        return SMVP_OK;
+    free_row_gather(h);
+    const size_t n = (size_t)std::max(h->nnz, 4);
+    const int index = row_gather_index(h);
+    if (hipMalloc((void **)&h->d_rg_ptr, ((size_t)h->rows + 4) * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&h->d_rg_pos, n * sizeof(int)) != hipSuccess ||
+        (index == smvp::kFlavorTjdsK && hipMalloc((void **)&h->d_rg_k, n * sizeof(int)) != hipSuccess))
+        return smvp::fail(SMVP_ERR_ALLOC, "TJDS: cannot allocate the row-gather plan");
+    // the true start_pos (d_plan_start_pos may carry the ref-quirks edit)
+    if (int rc = smvp::build_row_gather_plan(h->d_row_ind, h->d_start_pos, h->num_diag, h->nnz, h->rows, h->d_rg_ptr,
+                                             h->d_rg_pos, h->d_rg_k, nullptr))
+        return rc;
+    TjdsSource src;
+    src.pos = h->d_rg_pos, src.start_pos = h->d_start_pos, src.num_diag = h->num_diag;
+    return csr_create_impl(&h->rg, h->device, h->rows, std::max(h->cols, 1), h->nnz, h->d_rg_ptr, h->d_rg_k, h->d_val,
+                           SMVP_MEM_DEVICE, nullptr, index, &src);
+}
+
+int ensure_two_phase(smvp_tjds *h)
+{
+    if (h->inv)
+        return SMVP_OK;
+    const size_t n = (size_t)std::max(h->nnz, 4);
+    if ((!h->d_prod && hipMalloc((void **)&h->d_prod, n * sizeof(double)) != hipSuccess) ||
+        (!h->d_inv_pos && hipMalloc((void **)&h->d_inv_pos, n * sizeof(int)) != hipSuccess) ||
+        (!h->d_inv_ptr && hipMalloc((void **)&h->d_inv_ptr, ((size_t)h->rows + 4) * sizeof(int)) != hipSuccess))
+        return smvp::fail(SMVP_ERR_ALLOC, "TJDS: cannot allocate the two-phase buffers");
+    if (int rc = smvp::build_row_inverse(h->d_row_ind, h->nnz, h->rows, h->d_inv_ptr, h->d_inv_pos, nullptr))
+        return rc;
+    return csr_create_impl(&h->inv, h->device, h->rows, std::max(h->nnz, 1), h->nnz, h->d_inv_ptr, h->d_inv_pos, nullptr,
+                           SMVP_MEM_DEVICE, nullptr, smvp::kFlavorUnit);
+}
+
+int ensure_mode_plan(smvp_tjds *h)
+{
+    switch (h->mode) {
+    case SMVP_TJDS_MODE_ROW_GATHER:
+        return ensure_row_gather(h);
+    case SMVP_TJDS_MODE_TWO_PHASE:
+        return ensure_two_phase(h);
+    default:
+        return SMVP_OK;
+    }
+}
+
+bool overwrites_y(const smvp_tjds *h) { return h->mode != SMVP_TJDS_MODE_ATOMIC && !h->quirks; }
+
 }  // namespace
 
 extern "C" int smvp_tjds_create(smvp_tjds_t **out, int device, int rows, int cols, int nnz, int num_diag,
@@ -466,7 +625,7 @@ extern "C" int smvp_tjds_create(smvp_tjds_t **out, int device, int rows, int col
         return smvp::fail(SMVP_ERR_UNSUPPORTED, "smvp_tjds_create: %d entries: shard blocks this large by rows", nnz);
     if (int rc = usable_device(device))
         return rc;
-    HIP_TRY(hipSetDevice(device));
+    DeviceScope on(device);
 
     smvp_tjds *h = new smvp_tjds;
     h->device = device;
@@ -519,18 +678,8 @@ extern "C" int smvp_tjds_create(smvp_tjds_t **out, int device, int rows, int col
     }
     if (rc == SMVP_OK)
         rc = build_tjds_plan(h, false, 0, 0);
-    if (rc == SMVP_OK) {
-        const size_t n = (size_t)std::max(nnz, 1);
-        if (hipMalloc((void **)&h->d_prod, n * sizeof(double)) != hipSuccess ||
-            hipMalloc((void **)&h->d_inv_pos, n * sizeof(int)) != hipSuccess ||
-            hipMalloc((void **)&h->d_inv_ptr, ((size_t)rows + 1) * sizeof(int)) != hipSuccess)
-            rc = smvp::fail(SMVP_ERR_ALLOC, "smvp_tjds_create: cannot allocate the two-phase buffers");
-    }
     if (rc == SMVP_OK)
-        rc = smvp::build_row_inverse(h->d_row_ind, nnz, rows, h->d_inv_ptr, h->d_inv_pos, nullptr);
-    if (rc == SMVP_OK)
-        rc = csr_create_impl(&h->inv, device, rows, std::max(nnz, 1), nnz, h->d_inv_ptr, h->d_inv_pos, nullptr,
-                             SMVP_MEM_DEVICE, nullptr, true);
+        rc = ensure_mode_plan(h);
     if (rc != SMVP_OK) {
         smvp_tjds_destroy(h);
         return rc;
@@ -541,9 +690,15 @@ extern "C" int smvp_tjds_create(smvp_tjds_t **out, int device, int rows, int col
 
 extern "C" int smvp_tjds_set_mode(smvp_tjds_t *h, int mode)
 {
-    if (!h || mode < SMVP_TJDS_MODE_AUTO || mode > SMVP_TJDS_MODE_TWO_PHASE)
+    if (!h || mode < SMVP_TJDS_MODE_AUTO || mode > SMVP_TJDS_MODE_ROW_GATHER)
         return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_set_mode: bad argument");
-    h->mode = mode == SMVP_TJDS_MODE_AUTO ? SMVP_TJDS_MODE_TWO_PHASE : mode;
+    DeviceScope on(h->device);
+    const int before = h->mode;
+    h->mode = mode == SMVP_TJDS_MODE_AUTO ? SMVP_TJDS_MODE_ROW_GATHER : mode;
+    if (int rc = ensure_mode_plan(h)) {
+        h->mode = before;
+        return rc;
+    }
     return SMVP_OK;
 }
 
@@ -563,15 +718,15 @@ extern "C" int smvp_tjds_zero_y(smvp_tjds_t *h, double *d_y, void *stream)
 {
     if (!h || (h->rows > 0 && !d_y))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_zero_y: bad argument");
-    if (h->mode == SMVP_TJDS_MODE_TWO_PHASE && !h->quirks)
-        return SMVP_OK;  // the two-phase product overwrites y
+    if (overwrites_y(h))
+        return SMVP_OK;  // the row-gather and two-phase products overwrite y
     DeviceScope on(h->device);
     if (h->rows > 0)
         HIP_TRY(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)h->rows, (hipStream_t)stream));
     return SMVP_OK;
 }
 
-extern "C" int smvp_tjds_spmv(smvp_tjds_t *h, double *d_y, void *stream)
+static int tjds_spmv_impl(smvp_tjds_t *h, double *d_y, void *stream, unsigned long long *stamps)
 {
     if (!h || (h->rows > 0 && !d_y))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_spmv: bad argument");
@@ -580,6 +735,8 @@ extern "C" int smvp_tjds_spmv(smvp_tjds_t *h, double *d_y, void *stream)
     if (h->quirks && h->rows != h->cols)
         return smvp::fail(SMVP_ERR_UNSUPPORTED, "ref-quirks mode indexes the operand by row and needs a square matrix");
     DeviceScope on(h->device);
+    if (!h->quirks && h->mode == SMVP_TJDS_MODE_ROW_GATHER)
+        return csr_spmv_impl(h->rg, h->d_x_perm, d_y, stream, stamps);
     if (h->mode == SMVP_TJDS_MODE_TWO_PHASE && !h->quirks) {
         hipError_t e1 = smvp::launch_tjds_products(h->d_plan_start_pos, h->d_val, h->d_x_perm, h->d_prod, h->d_work,
                                                    h->nwork, h->cols, (hipStream_t)stream);
@@ -594,11 +751,21 @@ extern "C" int smvp_tjds_spmv(smvp_tjds_t *h, double *d_y, void *stream)
     return SMVP_OK;
 }
 
+extern "C" int smvp_tjds_spmv(smvp_tjds_t *h, double *d_y, void *stream)
+{
+    return tjds_spmv_impl(h, d_y, stream, nullptr);
+}
+
+static bool tjds_can_stamp(const smvp_tjds_t *h)
+{
+    return h && !h->quirks && h->mode == SMVP_TJDS_MODE_ROW_GATHER && csr_can_stamp(h->rg);
+}
+
 extern "C" int smvp_tjds_set_ref_quirks(smvp_tjds_t *h, int enable, int ref_num_tjdiag, int last_diag_single)
 {
     if (!h || (enable && ref_num_tjdiag < 0))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_set_ref_quirks: bad argument");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceScope on(h->device);
     return build_tjds_plan(h, enable != 0, ref_num_tjdiag, last_diag_single);
 }
 
@@ -607,21 +774,33 @@ extern "C" int smvp_tjds_describe(const smvp_tjds_t *h, char *kernel_name, size_
     if (!h)
         return smvp::fail(SMVP_ERR_INVALID, "null handle");
     if (kernel_name && cap) {
-        if (h->mode == SMVP_TJDS_MODE_TWO_PHASE && !h->quirks)
-            snprintf(kernel_name, cap, "tjds_colmajor_products + csr_stream_owner<4, true>");
-        else
+        if (h->quirks || h->mode == SMVP_TJDS_MODE_ATOMIC)
             snprintf(kernel_name, cap, "tjds_colmajor_scatter<%s>", h->quirks ? "true" : "false");
+        else if (h->mode == SMVP_TJDS_MODE_TWO_PHASE)
+            snprintf(kernel_name, cap, "tjds_colmajor_products + csr_stream_owner<%d, %d>", h->inv ? h->inv->vpt : 0,
+                     smvp::kFlavorUnit);
+        else
+            snprintf(kernel_name, cap, "csr_stream_owner<%d, %d>", h->rg ? h->rg->vpt : 0, h->rg ? h->rg->flavor : 0);
     }
     if (alg_bytes)
         *alg_bytes = 12.0 * h->planned_nnz + 4.0 * (h->num_diag + 1.0) + 8.0 * h->cols + 8.0 * h->rows;
     return SMVP_OK;
 }
 
+// tile size of the row-gather product (development knob; 256, 1024 or 2048 entries)
+extern "C" int smvp_tjds_set_tile(smvp_tjds_t *h, int entries_per_tile)
+{
+    if (!h || !h->rg)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_set_tile: the handle has no row-gather plan");
+    return smvp_csr_set_kernel(h->rg, SMVP_CSR_KERNEL_STREAM, entries_per_tile);
+}
+
 extern "C" void smvp_tjds_destroy(smvp_tjds_t *h)
 {
     if (!h)
         return;
-    (void)hipSetDevice(h->device);
+    DeviceScope on(h->device);
+    free_row_gather(h);
     if (h->own_perm && h->d_perm)
         (void)hipFree(h->d_perm);
     if (h->own_start_pos && h->d_start_pos)
@@ -685,6 +864,8 @@ extern "C" void smvp_run_opts_default(smvp_run_opts_t *o)
         return;
     memset(o, 0, sizeof *o);
     o->csr_kernel = SMVP_CSR_KERNEL_AUTO;
+    o->tjds_mode = SMVP_TJDS_MODE_AUTO;
+    o->timing = SMVP_TIMING_AUTO;
 }
 
 namespace {
@@ -781,10 +962,153 @@ int check_iterate(const smvp_run_opts_t *o, int rows, int cols)
 {
     if (o->iterate && rows != cols)
         return smvp::fail(SMVP_ERR_INVALID, "power iteration needs a square matrix (%d x %d given)", rows, cols);
+    if (o->timing < SMVP_TIMING_AUTO || o->timing > SMVP_TIMING_DEVICE)
+        return smvp::fail(SMVP_ERR_INVALID, "unknown timing method %d", o->timing);
+    return SMVP_OK;
+}
+
+thread_local smvp_run_info_t g_last_run = {SMVP_TIMING_EVENTS, 0, 0.0, 0.0};
+
+double host_ms()
+{
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC_RAW, &t);  // the reference's clock, main-cli.c:408
+    return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+
+// Per-product times of launches too short for an event pair to time.  The reference brackets its product with
+// clock_gettime (main-cli.c:408-419): nothing but the product is inside the window.  A hipEvent pair around a launch
+// of a few microseconds measures mostly the events themselves (an empty launch between two events reads 6.6 us on
+// MI355X, memplus.mtx's CSR kernel runs 3.8 us), so for such launches the kernel times itself: every wave writes the
+// constant-rate wall clock when it starts and when its last store has been acknowledged, stamp_reduce takes
+// max(last) - min(first) per product.  The products of a run are captured into one hipGraph (kStampRing products per
+// replay, their timing slots baked into the nodes) so that the host's launch rate is not what the run waits for.
+constexpr int kStampRing = 256;        // products per graph replay (even: power iteration swaps x and y)
+constexpr int kStampMaxSlots = 16384;  // waves per launch up to which the kernel times itself (4096 workgroups)
+
+struct StampTimer {
+    unsigned long long *d_stamps = nullptr, *d_first_last = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int exec_n = 0;
+    ~StampTimer()
+    {
+        if (exec)
+            (void)hipGraphExecDestroy(exec);
+        if (d_stamps)
+            (void)hipFree(d_stamps);
+        if (d_first_last)
+            (void)hipFree(d_first_last);
+    }
+};
+
+// `iters` products on s.stream, each timed on its own.  pre(y): work the reference keeps outside its window (clearing
+// y); product(x, y, stamps): the launches of one product.  stamp_slots > 0: the product can time itself on the device.
+template <class Pre, class Product>
+int run_timed_products(RunScratch &s, int rows, int iters, const smvp_run_opts_t *o, int stamp_slots, Pre pre, Product product)
+{
+    double *xc = s.d_x, *yc = s.d_y;
+    const bool stamped = o->timing != SMVP_TIMING_EVENTS && !o->iterate && stamp_slots > 0 &&
+                         (o->timing == SMVP_TIMING_DEVICE || stamp_slots <= kStampMaxSlots);
+    if (o->timing == SMVP_TIMING_DEVICE && !stamped)
+        return smvp::fail(SMVP_ERR_UNSUPPORTED, "device-side timing needs the tile kernel of one GPU and no --iterate");
+    g_last_run.timing = stamped ? SMVP_TIMING_DEVICE : SMVP_TIMING_EVENTS;
+    g_last_run.graph_replays = 0;
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    const double t0 = host_ms();
+    if (stamped) {
+        int dev = 0, khz = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+        if (khz <= 0)
+            return smvp::fail(SMVP_ERR_HIP, "the device reports no wall-clock rate");
+        g_last_run.device_clock_khz = khz;
+        StampTimer st;
+        const size_t per_product = (size_t)stamp_slots * 2;
+        const int ring = std::min(iters, kStampRing);
+        HIP_TRY(hipMalloc((void **)&st.d_stamps, sizeof(unsigned long long) * per_product * (size_t)ring));
+        HIP_TRY(hipMalloc((void **)&st.d_first_last, sizeof(unsigned long long) * 2 * (size_t)ring));
+        std::vector<unsigned long long> fl((size_t)ring * 2);
+        bool use_graph = getenv("SMVP_NO_GRAPH") == nullptr;
+        for (int i0 = 0; i0 < iters; i0 += ring) {
+            const int n = std::min(ring, iters - i0);
+            auto enqueue = [&]() -> int {
+                for (int k = 0; k < n; ++k) {
+                    if (int rc = pre(yc))
+                        return rc;
+                    if (int rc = product(xc, yc, st.d_stamps + per_product * (size_t)k))
+                        return rc;
+                }
+                return SMVP_OK;
+            };
+            if (use_graph && st.exec_n != n) {
+                if (st.exec)
+                    (void)hipGraphExecDestroy(st.exec);
+                st.exec = nullptr;
+                st.exec_n = 0;
+                hipGraph_t graph = nullptr;
+                bool ok = hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                int rc = ok ? enqueue() : SMVP_OK;
+                if (ok)
+                    ok = hipStreamEndCapture(s.stream, &graph) == hipSuccess && graph && rc == SMVP_OK;
+                if (ok)
+                    ok = hipGraphInstantiate(&st.exec, graph, nullptr, nullptr, 0) == hipSuccess;
+                if (graph)
+                    (void)hipGraphDestroy(graph);
+                if (rc != SMVP_OK)
+                    return rc;
+                if (!ok) {  // no graph support for this sequence: plain launches, still timed on the device
+                    (void)hipGetLastError();
+                    st.exec = nullptr;
+                    use_graph = false;
+                } else {
+                    st.exec_n = n;
+                }
+            }
+            if (use_graph) {
+                HIP_TRY(hipGraphLaunch(st.exec, s.stream));
+                ++g_last_run.graph_replays;
+            } else if (int rc = enqueue()) {
+                return rc;
+            }
+            HIP_TRY(smvp::launch_stamp_reduce(st.d_stamps, stamp_slots, n, st.d_first_last, s.stream));
+            HIP_TRY(hipMemcpyAsync(fl.data(), st.d_first_last, sizeof(unsigned long long) * 2 * (size_t)n,
+                                   hipMemcpyDeviceToHost, s.stream));
+            HIP_TRY(hipStreamSynchronize(s.stream));
+            for (int k = 0; k < n; ++k)
+                s.ms[(size_t)(i0 + k)] = (double)(fl[2 * (size_t)k + 1] - fl[2 * (size_t)k]) / (double)khz;
+        }
+        s.d_result = yc;
+    } else {
+        for (int i = 0; i < iters; ++i) {
+            if (int rc = pre(yc))
+                return rc;
+            HIP_TRY(hipEventRecord(ev_start(s, i), s.stream));
+            if (int rc = product(xc, yc, nullptr))
+                return rc;
+            if (o->iterate && o->normalize)
+                HIP_TRY(smvp::launch_normalize_max(yc, rows, s.d_norm, s.stream));
+            HIP_TRY(hipEventRecord(ev_stop(s, i), s.stream));
+            if (int rc = drain_ring(s, i, iters))
+                return rc;
+            s.d_result = yc;
+            if (o->iterate)
+                std::swap(xc, yc);  // x_{k+1} = y_k
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    g_last_run.wall_ms = host_ms() - t0;
     return SMVP_OK;
 }
 
 }  // namespace
+
+extern "C" int smvp_last_run_info(smvp_run_info_t *out)
+{
+    if (!out)
+        return smvp::fail(SMVP_ERR_INVALID, "null argument");
+    *out = g_last_run;
+    return SMVP_OK;
+}
 
 // opts.ngpus > 1: the same timed loop over row blocks on several GPUs; the window is the local products
 // plus the all-gather of y, the longest GPU counts (smvp_sharded.hip)
@@ -839,7 +1163,7 @@ extern "C" int smvp_csr_compute(const smvp_coo_t *coo, int rows, int cols, int n
         return sharded_compute(false, coo, rows, cols, nnz, iters, o, y, time_each_ms, stats);
     if (int rc = usable_device(o->device))
         return rc;
-    HIP_TRY(hipSetDevice(o->device));
+    DeviceScope on(o->device);
 
     RunScratch s;
     if (o->convert_on_device) {
@@ -869,24 +1193,16 @@ extern "C" int smvp_csr_compute(const smvp_coo_t *coo, int rows, int cols, int n
     if (int rc = prepare_run(s, rows, cols, iters, o))
         return rc;
 
-    double *xc = s.d_x, *yc = s.d_y;
-    for (int i = 0; i < iters; ++i) {
-        // the reference clears y before every product, outside its timed window
-        // (main-cli.c:405); the CSR kernels overwrite y, the clear is kept so a
-        // kernel that skipped a row could not hide behind the previous result
-        HIP_TRY(hipMemsetAsync(yc, 0, sizeof(double) * (size_t)std::max(rows, 1), s.stream));
-        HIP_TRY(hipEventRecord(ev_start(s, i), s.stream));
-        if (int rc = smvp_csr_spmv(s.csr, xc, yc, s.stream))
-            return rc;
-        if (o->iterate && o->normalize)
-            HIP_TRY(smvp::launch_normalize_max(yc, rows, s.d_norm, s.stream));
-        HIP_TRY(hipEventRecord(ev_stop(s, i), s.stream));
-        if (int rc = drain_ring(s, i, iters))
-            return rc;
-        s.d_result = yc;
-        if (o->iterate)
-            std::swap(xc, yc);  // x_{k+1} = y_k
-    }
+    // The reference clears y before every product, outside its timed window (main-cli.c:405).  Every CSR kernel
+    // here overwrites all of y, so nothing is cleared per product; y is poisoned with NaN once instead, so that a
+    // kernel that skipped a row could not hide behind a cleared (or an earlier) result.
+    HIP_TRY(hipMemsetAsync(s.d_y, 0xff, sizeof(double) * (size_t)std::max(rows, 1), s.stream));
+    smvp_csr_t *A = s.csr;
+    const int slots = csr_can_stamp(A) ? smvp::owner_stamp_slots(A->ntiles, A->flavor) : 0;
+    if (int rc = run_timed_products(
+            s, rows, iters, o, slots, [](double *) { return (int)SMVP_OK; },
+            [A, &s](const double *x, double *yy, unsigned long long *stamps) { return csr_spmv_impl(A, x, yy, s.stream, stamps); }))
+        return rc;
     return finish_run(s, rows, iters, y, time_each_ms, stats);
 }
 
@@ -910,7 +1226,7 @@ extern "C" int smvp_tjds_compute(const smvp_coo_t *coo, int rows, int cols, int 
     }
     if (int rc = usable_device(o->device))
         return rc;
-    HIP_TRY(hipSetDevice(o->device));
+    DeviceScope on(o->device);
 
     int num_diag = 0, ref_num = 0, last_single = 0;
     RunScratch s;
@@ -948,24 +1264,24 @@ extern "C" int smvp_tjds_compute(const smvp_coo_t *coo, int rows, int cols, int 
     if (int rc = smvp_tjds_set_x(s.tjds, s.d_x, s.stream))  // main-cli.c:907-923, setup
         return rc;
 
-    double *xc = s.d_x, *yc = s.d_y;
-    for (int i = 0; i < iters; ++i) {
-        if (int rc = smvp_tjds_zero_y(s.tjds, yc, s.stream))  // main-cli.c:1008, outside the window
+    if (o->tjds_mode != SMVP_TJDS_MODE_AUTO)
+        if (int rc = smvp_tjds_set_mode(s.tjds, o->tjds_mode))
             return rc;
-        HIP_TRY(hipEventRecord(ev_start(s, i), s.stream));
-        if (o->iterate && i > 0)  // a new operand: its permutation is part of this product
-            if (int rc = smvp_tjds_set_x(s.tjds, xc, s.stream))
-                return rc;
-        if (int rc = smvp_tjds_spmv(s.tjds, yc, s.stream))
-            return rc;
-        if (o->iterate && o->normalize)
-            HIP_TRY(smvp::launch_normalize_max(yc, rows, s.d_norm, s.stream));
-        HIP_TRY(hipEventRecord(ev_stop(s, i), s.stream));
-        if (int rc = drain_ring(s, i, iters))
-            return rc;
-        s.d_result = yc;
-        if (o->iterate)
-            std::swap(xc, yc);
-    }
+    HIP_TRY(hipMemsetAsync(s.d_y, 0xff, sizeof(double) * (size_t)std::max(rows, 1), s.stream));  // NaN, as in the CSR path
+    smvp_tjds_t *T = s.tjds;
+    const int slots = tjds_can_stamp(T) ? smvp::owner_stamp_slots(T->rg->ntiles, T->rg->flavor) : 0;
+    bool first = true;
+    const bool iterate = o->iterate != 0;
+    if (int rc = run_timed_products(
+            s, rows, iters, o, slots,
+            [T, &s](double *yy) { return smvp_tjds_zero_y(T, yy, s.stream); },  // main-cli.c:1008, outside the window
+            [T, &s, &first, iterate](const double *x, double *yy, unsigned long long *stamps) {
+                if (iterate && !first)  // a new operand: its permutation is part of this product
+                    if (int rc = smvp_tjds_set_x(T, x, s.stream))
+                        return rc;
+                first = false;
+                return tjds_spmv_impl(T, yy, s.stream, stamps);
+            }))
+        return rc;
     return finish_run(s, rows, iters, y, time_each_ms, stats);
 }

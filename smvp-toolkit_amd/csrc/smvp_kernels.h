@@ -9,6 +9,7 @@ constexpr int kStreamBlock = 256;   // threads per block, csr_stream_tiles
 constexpr int kLongRow = 32;        // segments longer than this are summed by a wavefront
 constexpr int kStreamOver = 1024;    // entries past its end a tile may finish its last row with, through LDS
 constexpr int kStreamTileGroup = 64;  // consecutive tiles per XCD turn (see tile_of_block)
+constexpr int kTjdsTileGroup = 16;    // ... for the tile-ordered TJDS stream
 constexpr int kTjdsBlock = 256;     // permuted columns per work item
 constexpr int kTjdsDiagChunk = 8;   // jagged diagonals per work item
 
@@ -17,9 +18,28 @@ hipError_t launch_csr_vector(int lanes_per_row, const int *row_ptr, const int *c
 hipError_t launch_csr_stream(int vpt, const int *row_ptr, const int *col_ind, const double *val,
                              const double *x, double *y, const int *tile_row, const int *carry_row,
                              double *carry, int rows, int nnz, int ntiles, hipStream_t stream);
-hipError_t launch_csr_stream_owner(int vpt, bool unit_values, const int *row_ptr, const int *col_ind,
-                                   const double *val, const double *x, double *y, const int *tile_row,
-                                   const int *tile_next, int rows, int nnz, int ntiles, hipStream_t stream);
+// what an entry of the owner kernel's stream is (see csr_stream_owner)
+constexpr int kFlavorCsr = 0;    // val[j] * x[col_ind[j]]
+constexpr int kFlavorUnit = 1;   // x[col_ind[j]]
+constexpr int kFlavorTjdsK = 2;  // val[pos[j]] * x_perm[col_ind[j]]   (col_ind = permuted column k)
+constexpr int kFlavorTjdsS = 3;  // the same entries, every tile's in TJDS order; col_ind = LDS slot | diagonal << kSlotBits
+constexpr int kSlotBits = 11;    // a tile holds at most 2048 entries
+
+struct OwnerLaunch {
+    const int *row_ptr = nullptr, *col_ind = nullptr;
+    const double *val = nullptr, *x = nullptr;
+    double *y = nullptr;
+    const int *tile_row = nullptr, *tile_next = nullptr;
+    const int *pos = nullptr;
+    const int *start_pos = nullptr;
+    unsigned long long *stamps = nullptr;  // owner_stamp_slots(ntiles) pairs, or nullptr
+    const int *ovf_ptr = nullptr, *ovf_pos = nullptr, *ovf_k = nullptr;  // kFlavorTjdsS
+    int rows = 0, nnz = 0, ntiles = 0;
+};
+hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hipStream_t stream);
+int owner_stamp_slots(int ntiles, int flavor);  // {first, last} tick pairs one stamped launch writes
+hipError_t launch_stamp_reduce(const unsigned long long *stamps, int slots_per_product, int products,
+                               unsigned long long *first_last, hipStream_t stream);
 hipError_t launch_tjds_products(const int *start_pos, const double *val, const double *x_perm, double *prod,
                                 const int4 *work, int nwork, int cols, hipStream_t stream);
 hipError_t launch_tjds_scatter(bool operand_by_row, const int *start_pos, const int *row_ind, const double *val,

@@ -196,19 +196,73 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_tiles(
 // by the whole workgroup straight from global memory; matrices with rows far
 // longer than that are planned onto the carry kernel above instead, which
 // spreads such a row over many workgroups.
-// UNIT = true is the same kernel with every matrix value taken as 1 (val is not
-// read): y[r] = sum of x[col_ind[j]] over the row.  The TJDS path uses it as its
-// second phase, with x = the per-entry products and col_ind = the row-inverted
-// index (see tjds_colmajor_products).
+//
+// FLAVOR selects what an "entry" is (owner_entry below):
+//   kFlavorCsr     CSR: value val[j], operand x[col_ind[j]]                       (main-cli.c:410-416)
+//   kFlavorUnit    every value 1 (val not read): y[r] = sum x[col_ind[j]]; second phase of the two-phase TJDS product
+//   kFlavorTjdsK   TJDS by rows: the stream lists, row by row, the TJDS positions p of the row's entries (`pos`) and
+//                  their permuted columns k (`col_ind`): value val[p] gathered from the jagged-diagonal array,
+//                  operand x_perm[k] (the one-kernel TJDS product, see ensure_row_gather in the engine)
+//   kFlavorTjdsS   the same rows, but inside every tile the entries are listed in TJDS order (ascending position):
+//                  the tile walks its piece of the jagged diagonals the way the format stores them -- neighbouring
+//                  lanes read neighbouring val / x_perm entries, lane t takes entries t, t + 256, ... of the tile --
+//                  and each product goes to the LDS slot of its row-major place (`col_ind` holds slot | diagonal << 11);
+//                  the entries a tile needs from beyond its end are kept a second time in row order (ovf_*)
 // ---------------------------------------------------------------------------
-template <int VPT, bool UNIT>
-__global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
-    const int *__restrict__ row_ptr, const int *__restrict__ col_ind, const double *__restrict__ val,
-    const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ tile_row,
-    const int *__restrict__ tile_next, int rows, int nnz, int ntiles, int tile_group)
+typedef int int4v __attribute__((ext_vector_type(4)));               // clang vectors: what the non-temporal builtins take
+
+struct OwnerArgs {
+    const int *row_ptr;       // rows + 1 segment bounds over the entry stream
+    const int *col_ind;       // Csr/Unit: column; TjdsK: permuted column k
+    const double *val;        // Csr: values in stream order; Tjds*: the TJDS val array (gathered through pos)
+    const double *x;          // operand (Tjds*: x_perm)
+    double *y;
+    const int *tile_row;
+    const int *tile_next;
+    const int *pos;                 // Tjds*: TJDS position of each stream entry
+    const int *start_pos;           // TjdsS
+    unsigned long long *stamps;     // optional: per-wave {first, last} wall-clock ticks of this launch
+    int rows, nnz, ntiles, tile_group;
+    int stream_nt;                  // Tjds*: load the pos / diag / col_ind streams non-temporally (read once; keeps L2 for the gathers)
+    const int *ovf_ptr;             // TjdsS: ntiles + 1 bounds of the tiles' overflow entries in ovf_pos / ovf_k
+    const int *ovf_pos;             // TjdsS: TJDS position ...
+    const int *ovf_k;               // TjdsS: ... and permuted column of the entries [e, tile_next) of each tile, row order
+};
+
+// one entry's product the slow way (tile tails, overflow beyond one block width, giant rows)
+template <int FLAVOR>
+__device__ __forceinline__ double owner_product_slow(const OwnerArgs &a, long long j)
+{
+    if constexpr (FLAVOR == kFlavorCsr)
+        return a.val[j] * a.x[a.col_ind[j]];
+    else if constexpr (FLAVOR == kFlavorUnit)
+        return a.x[a.col_ind[j]];
+    else if constexpr (FLAVOR == kFlavorTjdsK)
+        return a.val[a.pos[j]] * a.x[a.col_ind[j]];
+    else {
+        const int p = a.pos[j];
+        return a.val[p] * a.x[p - a.start_pos[(unsigned)a.col_ind[j] >> kSlotBits]];
+    }
+}
+
+// product of overflow entry `i` of tile b (stream entry e + i, the i-th entry past the tile's end)
+template <int FLAVOR>
+__device__ __forceinline__ double owner_overflow_product(const OwnerArgs &a, int ovf_base, int e, int i)
+{
+    if constexpr (FLAVOR == kFlavorTjdsS)
+        return a.val[a.ovf_pos[ovf_base + i]] * a.x[a.ovf_k[ovf_base + i]];
+    else
+        return owner_product_slow<FLAVOR>(a, (long long)e + i);
+}
+
+template <int VPT, int FLAVOR>
+__global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(const OwnerArgs a)
 {
     constexpr int TILE = kStreamBlock * VPT;
     constexpr int QCAP = (TILE + kStreamOver) / kLongRow + 1;
+    constexpr bool TJDS = FLAVOR == kFlavorTjdsK || FLAVOR == kFlavorTjdsS;
+    constexpr bool SORTED = FLAVOR == kFlavorTjdsS;  // entries in TJDS order inside the tile, lane-strided
+    static_assert(TILE <= (1 << kSlotBits), "slot bits");
     __shared__ double prod[TILE + kStreamOver];
     __shared__ int long_rows[QCAP];  // rows longer than kLongRow and their LDS segments, filled in phase 2b
     __shared__ int long_a[QCAP];
@@ -216,91 +270,189 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     __shared__ int long_count;
     __shared__ double wave_sum[kStreamBlock / 64];
 
-    const int b = tile_of_block(blockIdx.x, tile_group);
-    if (b >= ntiles)
-        return;
     const int t = threadIdx.x;
+    // optional device-side timing: every wave notes when it started and (after its last store has been
+    // acknowledged) when it finished; max(last) - min(first) over the launch is the product's own duration,
+    // free of launch and event overhead (the engine reduces the slots, see stamp_reduce)
+    unsigned long long *const stamp = a.stamps ? a.stamps + 2 * ((size_t)blockIdx.x * (kStreamBlock / 64) + (t >> 6)) : nullptr;
+    if (stamp && (t & 63) == 0)
+        stamp[0] = wall_clock64();
+#define SMVP_OWNER_EXIT()                                         \
+    do {                                                          \
+        if (stamp) {                                              \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      \
+            if ((t & 63) == 0)                                    \
+                stamp[1] = wall_clock64();                        \
+        }                                                         \
+        return;                                                   \
+    } while (0)
+
+    const int b = tile_of_block(blockIdx.x, a.tile_group);
+    if (b >= a.ntiles)
+        SMVP_OWNER_EXIT();
+    const int nnz = a.nnz;
     const long long s = (long long)b * TILE;
     const long long j0 = s + (long long)t * VPT;
 
     // ---- phase 1: stream + gather + multiply.  Straight-line code, ordered so that nothing waits on more
-    // than one dependent round trip: the tile's own col_ind / val loads go out first (they depend on nothing
+    // than one dependent round trip: the tile's own index / value loads go out first (they depend on nothing
     // but the block index), then the plan words, then row_ptr for phase 2 and the overflow entries, then ALL
-    // x gathers (col_ind -> x is the one dependence that cannot be avoided).
+    // gathers (index -> operand is the one dependence that cannot be avoided).
     const bool whole = j0 + VPT <= (long long)nnz;  // this lane's entries all exist (always, except in the last tile)
-    int c[VPT];
+    int c[VPT];     // operand index
+    int pj[VPT];    // Tjds*: position in val
     double v[VPT];
-    if (whole) {
+    const bool full_tile = s + TILE <= (long long)nnz;
+    if constexpr (SORTED) {
+        if (full_tile) {
+#pragma unroll
+            for (int k = 0; k < VPT; ++k) {
+                if (a.stream_nt) {
+                    pj[k] = __builtin_nontemporal_load(a.pos + s + k * kStreamBlock + t);
+                    c[k] = __builtin_nontemporal_load(a.col_ind + s + k * kStreamBlock + t);
+                } else {
+                    pj[k] = a.pos[s + k * kStreamBlock + t];
+                    c[k] = a.col_ind[s + k * kStreamBlock + t];  // slot | diagonal << kSlotBits
+                }
+            }
+        }
+    } else if (whole) {
         if constexpr (VPT >= 4) {
 #pragma unroll
             for (int k = 0; k < VPT; k += 4)
-                *reinterpret_cast<int4 *>(&c[k]) = *reinterpret_cast<const int4 *>(col_ind + j0 + k);
-            if (!UNIT) {
+                *reinterpret_cast<int4 *>(&c[k]) = *reinterpret_cast<const int4 *>(a.col_ind + j0 + k);
+            if constexpr (TJDS) {
+                if (a.stream_nt) {
+#pragma unroll
+                    for (int k = 0; k < VPT; k += 4)
+                        *reinterpret_cast<int4v *>(&pj[k]) = __builtin_nontemporal_load(reinterpret_cast<const int4v *>(a.pos + j0 + k));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < VPT; k += 4)
+                        *reinterpret_cast<int4 *>(&pj[k]) = *reinterpret_cast<const int4 *>(a.pos + j0 + k);
+                }
+            }
+            if constexpr (FLAVOR == kFlavorCsr) {
 #pragma unroll
                 for (int k = 0; k < VPT; k += 2)
-                    *reinterpret_cast<double2 *>(&v[k]) = *reinterpret_cast<const double2 *>(val + j0 + k);
+                    *reinterpret_cast<double2 *>(&v[k]) = *reinterpret_cast<const double2 *>(a.val + j0 + k);
             }
         } else {  // VPT == 1: 256-entry tiles for matrices too small to fill the chip with 1024-entry ones
-            c[0] = col_ind[j0];
-            if (!UNIT)
-                v[0] = val[j0];
+            c[0] = a.col_ind[j0];
+            if constexpr (TJDS)
+                pj[0] = a.pos[j0];
+            if constexpr (FLAVOR == kFlavorCsr)
+                v[0] = a.val[j0];
         }
     }
-    const int rlo = tile_row[b];
-    const int rhi = tile_row[b + 1];
+    const int rlo = a.tile_row[b];
+    const int rhi = a.tile_row[b + 1];
     if (rlo == rhi)
-        return;  // all of this tile continues a row owned by an earlier tile
+        SMVP_OWNER_EXIT();  // all of this tile continues a row owned by an earlier tile
     const int lo = (int)s;  // nnz < 2^31
     const int e = (int)(s + TILE < (long long)nnz ? s + TILE : (long long)nnz);
-    const int zend = tile_next[b];  // row_ptr[rhi]: end of the last owned row, >= e
+    const int zend = a.tile_next[b];  // row_ptr[rhi]: end of the last owned row, >= e
     const int ext = zend - e;
     const bool giant = ext > kStreamOver;
     if (t == 0)
         long_count = 0;
     const bool over0 = !giant && t < ext;  // this lane fetches overflow entry e + t
-    const bool full_tile = s + TILE <= (long long)nnz;
     double p[VPT];
     double po = 0.0;
     int rp_a = 0, rp_b = 0;
-    if (whole) {
-        if (rlo + t < rhi) {  // this lane's first row in phase 2
-            rp_a = row_ptr[rlo + t];
-            rp_b = row_ptr[rlo + t + 1];
+    int ovf_base = 0;
+    if constexpr (SORTED)
+        ovf_base = a.ovf_ptr[b];
+    if constexpr (SORTED) {
+        if (full_tile && rlo + t < rhi) {
+            rp_a = a.row_ptr[rlo + t];
+            rp_b = a.row_ptr[rlo + t + 1];
         }
-        int co = 0;
+        int co = 0, pjo = 0;
+        if (over0) {
+            pjo = a.ovf_pos[ovf_base + t];
+            co = a.ovf_k[ovf_base + t];
+        }
+        if (full_tile) {
+            int slot[VPT];
+#pragma unroll
+            for (int k = 0; k < VPT; ++k) {
+                slot[k] = c[k] & ((1 << kSlotBits) - 1);
+                c[k] = pj[k] - a.start_pos[(unsigned)c[k] >> kSlotBits];
+            }
+            double xk[VPT];
+#pragma unroll
+            for (int k = 0; k < VPT; ++k)
+                v[k] = a.val[pj[k]];
+            const double vo = over0 ? a.val[pjo] : 0.0;
+#pragma unroll
+            for (int k = 0; k < VPT; ++k)
+                xk[k] = a.x[c[k]];
+            const double xo = over0 ? a.x[co] : 0.0;
+#pragma unroll
+            for (int k = 0; k < VPT; ++k)
+                prod[slot[k]] = v[k] * xk[k];
+            po = vo * xo;
+        } else {  // the last, partial tile
+            for (int k = 0; k < VPT; ++k) {
+                const long long j = s + k * kStreamBlock + t;
+                if (j < (long long)nnz)
+                    prod[a.col_ind[j] & ((1 << kSlotBits) - 1)] = owner_product_slow<FLAVOR>(a, j);
+            }
+            if (over0)
+                po = a.val[pjo] * a.x[co];
+        }
+    } else if (whole) {
+        if (rlo + t < rhi) {  // this lane's first row in phase 2
+            rp_a = a.row_ptr[rlo + t];
+            rp_b = a.row_ptr[rlo + t + 1];
+        }
+        int co = 0, pjo = 0;
         double vo = 0.0;
         if (over0) {
-            co = col_ind[e + t];
-            vo = UNIT ? 1.0 : val[e + t];
+            co = a.col_ind[e + t];
+            if constexpr (TJDS)
+                pjo = a.pos[e + t];
+            if constexpr (FLAVOR == kFlavorCsr)
+                vo = a.val[e + t];
         }
         double xk[VPT];
+        if constexpr (TJDS) {
+#pragma unroll
+            for (int k = 0; k < VPT; ++k)
+                v[k] = a.val[pj[k]];
+            if (over0)
+                vo = a.val[pjo];
+        }
 #pragma unroll
         for (int k = 0; k < VPT; ++k)
-            xk[k] = x[c[k]];
-        const double xo = over0 ? x[co] : 0.0;
+            xk[k] = a.x[c[k]];
+        const double xo = over0 ? a.x[co] : 0.0;
 #pragma unroll
         for (int k = 0; k < VPT; ++k)
-            p[k] = UNIT ? xk[k] : v[k] * xk[k];
-        po = UNIT ? xo : vo * xo;
+            p[k] = FLAVOR == kFlavorUnit ? xk[k] : v[k] * xk[k];
+        po = FLAVOR == kFlavorUnit ? xo : vo * xo;
     } else {
 #pragma unroll
         for (int k = 0; k < VPT; ++k)
-            p[k] = (j0 + k < (long long)nnz) ? (UNIT ? 1.0 : val[j0 + k]) * x[col_ind[j0 + k]] : 0.0;
+            p[k] = (j0 + k < (long long)nnz) ? owner_product_slow<FLAVOR>(a, j0 + k) : 0.0;
         if (over0)
-            po = (UNIT ? 1.0 : val[e + t]) * x[col_ind[e + t]];
+            po = owner_product_slow<FLAVOR>(a, e + t);
     }
-    if constexpr (VPT >= 2) {
+    if constexpr (!SORTED) {
+        if constexpr (VPT >= 2) {
 #pragma unroll
-        for (int k = 0; k < VPT; k += 2)
-            *reinterpret_cast<double2 *>(&prod[t * VPT + k]) = make_double2(p[k], p[k + 1]);
-    } else {
-        prod[t] = p[0];
+            for (int k = 0; k < VPT; k += 2)
+                *reinterpret_cast<double2 *>(&prod[t * VPT + k]) = make_double2(p[k], p[k + 1]);
+        } else {
+            prod[t] = p[0];
+        }
     }
     if (over0)
         prod[e - lo + t] = po;
     if (!giant)  // rare: the last row runs more than one block width past the tile
         for (int i = t + kStreamBlock; i < ext; i += kStreamBlock)
-            prod[e - lo + i] = (UNIT ? 1.0 : val[e + i]) * x[col_ind[e + i]];
+            prod[e - lo + i] = owner_overflow_product<FLAVOR>(a, ovf_base, e, i);
     __syncthreads();
 
     // ---- phase 2b: one lane per owned row; its bounds were fetched with the tile (no global read after
@@ -310,18 +462,18 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
         if (giant && r == last)
             continue;
         const bool pre = full_tile && r == rlo + t;
-        const int a = (pre ? rp_a : row_ptr[r]) - lo;
-        const int z = (pre ? rp_b : row_ptr[r + 1]) - lo;
-        if (z - a <= kLongRow) {
+        const int ra = (pre ? rp_a : a.row_ptr[r]) - lo;
+        const int rz = (pre ? rp_b : a.row_ptr[r + 1]) - lo;
+        if (rz - ra <= kLongRow) {
             double acc = 0.0;
-            for (int i = a; i < z; ++i)
+            for (int i = ra; i < rz; ++i)
                 acc += prod[i];
-            __builtin_nontemporal_store(acc, &y[r]);
+            __builtin_nontemporal_store(acc, &a.y[r]);
         } else {
             const int q = atomicAdd(&long_count, 1);
             long_rows[q] = r;
-            long_a[q] = a;
-            long_z[q] = z;
+            long_a[q] = ra;
+            long_z[q] = rz;
         }
     }
     __syncthreads();
@@ -337,28 +489,25 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
             acc += prod[i];
         acc = shfl_down_sum<64>(acc);
         if (lane == 0)
-            y[long_rows[q]] = acc;
+            a.y[long_rows[q]] = acc;
     }
 
     // ---- phase 2d: a last row that runs far past the tile: LDS part + the rest from global memory
     if (giant) {
-        const int a = row_ptr[last];
+        const int ra = a.row_ptr[last];
         double acc = 0.0;
-        for (int i = a - lo + t; i < e - lo; i += kStreamBlock)
+        for (int i = ra - lo + t; i < e - lo; i += kStreamBlock)
             acc += prod[i];
         for (int j = e + t; j < zend; j += 4 * kStreamBlock) {
-            int cg[4];
-            double vg[4];
+            double pg[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int jj = j + u * kStreamBlock;
-                const bool in = jj < zend;
-                cg[u] = in ? col_ind[jj] : 0;
-                vg[u] = in ? (UNIT ? 1.0 : val[jj]) : 0.0;
+                pg[u] = jj < zend ? owner_overflow_product<FLAVOR>(a, ovf_base, e, jj - e) : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                acc += (j + u * kStreamBlock < zend) ? vg[u] * x[cg[u]] : 0.0;
+                acc += pg[u];
         }
         acc = shfl_down_sum<64>(acc);
         if (lane == 0)
@@ -369,8 +518,43 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
 #pragma unroll
             for (int w = 0; w < kStreamBlock / 64; ++w)
                 total += wave_sum[w];
-            y[last] = total;
+            a.y[last] = total;
         }
+    }
+    SMVP_OWNER_EXIT();
+#undef SMVP_OWNER_EXIT
+}
+
+// One workgroup per product of a stamped run: min of the waves' first ticks, max of their last.
+__global__ __launch_bounds__(256) void stamp_reduce(const unsigned long long *__restrict__ stamps, int slots_per_product,
+                                                    unsigned long long *__restrict__ first_last)
+{
+    __shared__ unsigned long long lo_s[256 / 64], hi_s[256 / 64];
+    const unsigned long long *s = stamps + (size_t)blockIdx.x * slots_per_product * 2;
+    unsigned long long lo = ~0ull, hi = 0ull;
+    for (int i = threadIdx.x; i < slots_per_product; i += 256) {
+        const unsigned long long f = s[2 * i], l = s[2 * i + 1];
+        lo = f < lo ? f : lo;
+        hi = l > hi ? l : hi;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long ol = __shfl_down(lo, off, 64), oh = __shfl_down(hi, off, 64);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        lo_s[threadIdx.x >> 6] = lo;
+        hi_s[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 256 / 64; ++w) {
+            lo = lo_s[w] < lo ? lo_s[w] : lo;
+            hi = hi_s[w] > hi ? hi_s[w] : hi;
+        }
+        first_last[2 * blockIdx.x] = lo;
+        first_last[2 * blockIdx.x + 1] = hi;
     }
 }
 
@@ -557,13 +741,13 @@ hipError_t launch_csr_vector(int lanes_per_row, const int *row_ptr, const int *c
 
 // Tiles per XCD turn for a launch of `ntiles` tiles: kStreamTileGroup, smaller for small matrices so that
 // the grid (rounded up to a multiple of 8 * group) is not mostly empty blocks.
-static int tile_group(int ntiles)
+static int tile_group(int ntiles, int wanted = kStreamTileGroup)
 {
-    static const int g = [] {
+    static const int env = [] {
         const char *e = getenv("SMVP_TILE_GROUP");  // development switch
-        const int v = e ? atoi(e) : kStreamTileGroup;
-        return v >= 1 ? v : 1;
+        return e ? atoi(e) : 0;
     }();
+    const int g = env >= 1 ? env : wanted;
     const int fit = ntiles / 64;
     return fit < 1 ? 1 : (fit < g ? fit : g);
 }
@@ -599,32 +783,63 @@ hipError_t launch_csr_stream(int vpt, const int *row_ptr, const int *col_ind, co
     return e;
 }
 
-hipError_t launch_csr_stream_owner(int vpt, bool unit_values, const int *row_ptr, const int *col_ind,
-                                   const double *val, const double *x, double *y, const int *tile_row,
-                                   const int *tile_next, int rows, int nnz, int ntiles, hipStream_t stream)
+// grid of a launch of `ntiles` tiles (a multiple of 8 * group, see tile_of_block)
+static unsigned owner_grid(int ntiles, int group) { return (unsigned)((ntiles + 8 * group - 1) / (8 * group)) * 8u * group; }
+
+// tiles per XCD turn by flavour: the tile-ordered TJDS stream re-uses val lines between neighbouring tiles and does
+// best when an XCD comes back to a neighbourhood soon (measured on memplus x944, 2048-entry tiles: group 16 / 32 /
+// 64 / 128 -> 0.592 / 0.596 / 0.612 / 0.601 ms); CSR measured best at 64 (profiles/r01_tile_group_sweep.txt)
+static int flavor_group(int flavor) { return flavor == kFlavorTjdsS ? kTjdsTileGroup : kStreamTileGroup; }
+
+int owner_stamp_slots(int ntiles, int flavor)
 {
-    if (rows <= 0)
+    return (int)owner_grid(ntiles, tile_group(ntiles, flavor_group(flavor))) * (kStreamBlock / 64);
+}
+
+hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hipStream_t stream)
+{
+    if (l.rows <= 0)
         return hipSuccess;
-    const int group = tile_group(ntiles);
-    const dim3 grid((unsigned)((ntiles + 8 * group - 1) / (8 * group)) * 8u * group);
-#define SMVP_OWNER(V, U)                                                                                          \
-    hipLaunchKernelGGL((csr_stream_owner<V, U>), grid, dim3(kStreamBlock), 0, stream, row_ptr, col_ind, val, x, y, \
-                       tile_row, tile_next, rows, nnz, ntiles, group)
-    if (vpt == 1 && !unit_values)
-        SMVP_OWNER(1, false);
-    else if (vpt == 1 && unit_values)
-        SMVP_OWNER(1, true);
-    else if (vpt == 4 && !unit_values)
-        SMVP_OWNER(4, false);
-    else if (vpt == 8 && !unit_values)
-        SMVP_OWNER(8, false);
-    else if (vpt == 4 && unit_values)
-        SMVP_OWNER(4, true);
-    else if (vpt == 8 && unit_values)
-        SMVP_OWNER(8, true);
-    else
-        return hipErrorInvalidValue;
+    const int group = tile_group(l.ntiles, flavor_group(flavor));
+    const dim3 grid(owner_grid(l.ntiles, group));
+    OwnerArgs a;
+    a.row_ptr = l.row_ptr, a.col_ind = l.col_ind, a.val = l.val, a.x = l.x, a.y = l.y;
+    a.tile_row = l.tile_row, a.tile_next = l.tile_next, a.pos = l.pos, a.start_pos = l.start_pos;
+    a.stamps = l.stamps;
+    a.rows = l.rows, a.nnz = l.nnz, a.ntiles = l.ntiles, a.tile_group = group;
+    static const int nt = [] {
+        const char *e = getenv("SMVP_TJDS_NT");  // development switch
+        return e ? atoi(e) : 0;
+    }();
+    a.stream_nt = nt;
+    a.ovf_ptr = l.ovf_ptr, a.ovf_pos = l.ovf_pos, a.ovf_k = l.ovf_k;
+#define SMVP_OWNER(V, F)                                                                             \
+    if (vpt == V && flavor == F) {                                                                   \
+        hipLaunchKernelGGL((csr_stream_owner<V, F>), grid, dim3(kStreamBlock), 0, stream, a);        \
+        return hipGetLastError();                                                                    \
+    }
+    SMVP_OWNER(1, kFlavorCsr)
+    SMVP_OWNER(4, kFlavorCsr)
+    SMVP_OWNER(8, kFlavorCsr)
+    SMVP_OWNER(1, kFlavorUnit)
+    SMVP_OWNER(4, kFlavorUnit)
+    SMVP_OWNER(8, kFlavorUnit)
+    SMVP_OWNER(1, kFlavorTjdsK)
+    SMVP_OWNER(4, kFlavorTjdsK)
+    SMVP_OWNER(8, kFlavorTjdsK)
+    SMVP_OWNER(1, kFlavorTjdsS)
+    SMVP_OWNER(4, kFlavorTjdsS)
+    SMVP_OWNER(8, kFlavorTjdsS)
 #undef SMVP_OWNER
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_stamp_reduce(const unsigned long long *stamps, int slots_per_product, int products,
+                               unsigned long long *first_last, hipStream_t stream)
+{
+    if (products <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(stamp_reduce, dim3(products), dim3(256), 0, stream, stamps, slots_per_product, first_last);
     return hipGetLastError();
 }
 

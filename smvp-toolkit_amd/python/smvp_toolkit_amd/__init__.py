@@ -22,7 +22,8 @@ MM_COULD_NOT_READ_FILE, MM_PREMATURE_EOF, MM_NOT_MTX, MM_NO_HEADER, MM_UNSUPPORT
 CSR_KERNEL_AUTO, CSR_KERNEL_VECTOR, CSR_KERNEL_STREAM, CSR_KERNEL_STREAM_CARRY = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 SYNTH_MEMPLUS_SHAPED, SYNTH_UNIFORM = 1, 2
-TJDS_MODE_AUTO, TJDS_MODE_ATOMIC, TJDS_MODE_TWO_PHASE = 0, 1, 2
+TJDS_MODE_AUTO, TJDS_MODE_ATOMIC, TJDS_MODE_TWO_PHASE, TJDS_MODE_ROW_GATHER = 0, 1, 2, 3
+TIMING_AUTO, TIMING_EVENTS, TIMING_DEVICE = 0, 1, 2
 
 COO_DTYPE = np.dtype([("row", "<i4"), ("col", "<i4"), ("val", "<f8")], align=True)
 
@@ -34,7 +35,12 @@ class TimeStats(C.Structure):
 class RunOpts(C.Structure):
     _fields_ = [("device", C.c_int), ("csr_kernel", C.c_int), ("csr_param", C.c_int),
                 ("tjds_ref_quirks", C.c_int), ("convert_on_device", C.c_int), ("ngpus", C.c_int),
-                ("iterate", C.c_int), ("normalize", C.c_int), ("x", C.c_void_p)]
+                ("iterate", C.c_int), ("normalize", C.c_int), ("tjds_mode", C.c_int), ("timing", C.c_int),
+                ("x", C.c_void_p)]
+
+
+class RunInfo(C.Structure):
+    _fields_ = [("timing", C.c_int), ("graph_replays", C.c_int), ("wall_ms", C.c_double), ("device_clock_khz", C.c_double)]
 
 
 class SmvpError(RuntimeError):
@@ -56,10 +62,10 @@ EXPORTS = [
     "smvp_csr_create", "smvp_csr_set_kernel", "smvp_csr_get_kernel", "smvp_csr_spmv",
     "smvp_csr_describe", "smvp_csr_destroy",
     "smvp_tjds_create", "smvp_tjds_set_x", "smvp_tjds_zero_y", "smvp_tjds_spmv",
-    "smvp_tjds_set_ref_quirks", "smvp_tjds_set_mode", "smvp_tjds_describe", "smvp_tjds_destroy",
+    "smvp_tjds_set_ref_quirks", "smvp_tjds_set_mode", "smvp_tjds_set_tile", "smvp_tjds_describe", "smvp_tjds_destroy",
     "smvp_csr_sharded_create", "smvp_tjds_sharded_create", "smvp_sharded_set_x", "smvp_sharded_spmv",
     "smvp_sharded_synchronize", "smvp_sharded_feed_back", "smvp_sharded_get_y", "smvp_sharded_info", "smvp_sharded_destroy",
-    "smvp_run_opts_default", "smvp_csr_compute", "smvp_tjds_compute",
+    "smvp_run_opts_default", "smvp_csr_compute", "smvp_tjds_compute", "smvp_last_run_info",
     "smvp_time_stats", "smvp_generate_report_text",
     "smvp_synth_row_lengths", "smvp_synth_fill", "smvp_partition_rows",
 ]
@@ -89,6 +95,8 @@ def lib():
         L.smvp_tjds_spmv.argtypes = [vp, vp, vp]
         L.smvp_tjds_set_ref_quirks.argtypes = [vp, ci, ci, ci]
         L.smvp_tjds_set_mode.argtypes = [vp, ci]
+        L.smvp_tjds_set_tile.argtypes = [vp, ci]
+        L.smvp_last_run_info.argtypes = [C.POINTER(RunInfo)]
         L.smvp_tjds_describe.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double)]
         L.smvp_tjds_destroy.argtypes = [vp]
         L.smvp_tjds_destroy.restype = None
@@ -376,6 +384,9 @@ class TjdsMatrix:
     def set_mode(self, mode):
         _check(lib().smvp_tjds_set_mode(self._h, mode), "smvp_tjds_set_mode")
 
+    def set_tile(self, entries_per_tile):
+        _check(lib().smvp_tjds_set_tile(self._h, entries_per_tile), "smvp_tjds_set_tile")
+
     def set_ref_quirks(self, enable=True):
         _check(lib().smvp_tjds_set_ref_quirks(self._h, int(enable), self._t.ref_num_tjdiag,
                                               self._t.last_diag_single), "smvp_tjds_set_ref_quirks")
@@ -455,12 +466,13 @@ class ShardedMatrix:
 
 # ------------------------------------------------- reference-shaped entry points
 def _run_opts(device, csr_kernel, csr_param, ref_quirks, x, device_convert=False, ngpus=0, iterate=False,
-              normalize=False):
+              normalize=False, tjds_mode=TJDS_MODE_AUTO, timing=TIMING_AUTO):
     o = RunOpts()
     lib().smvp_run_opts_default(C.byref(o))
     o.device, o.csr_kernel, o.csr_param, o.tjds_ref_quirks = device, csr_kernel, csr_param, int(ref_quirks)
     o.convert_on_device, o.ngpus = int(device_convert), int(ngpus)
     o.iterate, o.normalize = int(iterate), int(normalize)
+    o.tjds_mode, o.timing = int(tjds_mode), int(timing)
     keep = None
     if x is not None:
         keep = _arr(x, np.float64)
@@ -468,29 +480,37 @@ def _run_opts(device, csr_kernel, csr_param, ref_quirks, x, device_convert=False
     return o, keep
 
 
+def last_run_info():
+    """How the last *_compute on this thread timed its products -> RunInfo (timing, graph_replays, wall_ms, ...)."""
+    r = RunInfo()
+    _check(lib().smvp_last_run_info(C.byref(r)), "smvp_last_run_info")
+    return r
+
+
 def csr_compute(coo, rows, cols, iters=1, device=0, kernel=CSR_KERNEL_AUTO, param=0, x=None, device_convert=False,
-                ngpus=0, iterate=False, normalize=False):
+                ngpus=0, iterate=False, normalize=False, timing=TIMING_AUTO):
     """smvp_csr_compute: COO in, (y, per-iteration ms, TimeStats) out."""
     nnz = len(coo)
     coo = _arr(coo, COO_DTYPE)
     y = np.zeros(max(rows, 1), dtype=np.float64)
     ms = np.zeros(iters, dtype=np.float64)
     st = TimeStats()
-    o, keep = _run_opts(device, kernel, param, False, x, device_convert, ngpus, iterate, normalize)
+    o, keep = _run_opts(device, kernel, param, False, x, device_convert, ngpus, iterate, normalize, timing=timing)
     _check(lib().smvp_csr_compute(_p(coo), rows, cols, nnz, iters, C.byref(o), _p(y), _p(ms), C.byref(st)),
            "smvp_csr_compute")
     return y[:rows], ms, st
 
 
 def tjds_compute(coo, rows, cols, iters=1, device=0, ref_quirks=False, x=None, device_convert=False, ngpus=0,
-                 iterate=False, normalize=False):
+                 iterate=False, normalize=False, mode=TJDS_MODE_AUTO, timing=TIMING_AUTO):
     """smvp_tjds_compute: COO in, (y, per-iteration ms, TimeStats) out."""
     nnz = len(coo)
     coo = _arr(coo, COO_DTYPE)
     y = np.zeros(max(rows, 1), dtype=np.float64)
     ms = np.zeros(iters, dtype=np.float64)
     st = TimeStats()
-    o, keep = _run_opts(device, CSR_KERNEL_AUTO, 0, ref_quirks, x, device_convert, ngpus, iterate, normalize)
+    o, keep = _run_opts(device, CSR_KERNEL_AUTO, 0, ref_quirks, x, device_convert, ngpus, iterate, normalize,
+                        tjds_mode=mode, timing=timing)
     _check(lib().smvp_tjds_compute(_p(coo), rows, cols, nnz, iters, C.byref(o), _p(y), _p(ms), C.byref(st)),
            "smvp_tjds_compute")
     return y[:rows], ms, st

@@ -141,15 +141,44 @@ def test_auto_plan_choice(torch):
         A.close()
 
 
+TJDS_MODES = [sm.TJDS_MODE_ROW_GATHER, sm.TJDS_MODE_TWO_PHASE, sm.TJDS_MODE_ATOMIC]
+# the one-kernel product: (index form of its stream, entries per tile); "sorted" = every tile in TJDS order (default)
+TJDS_GATHER_VARIANTS = [("sorted", 0), ("sorted", 256), ("sorted", 1024), ("sorted", 2048), ("k32", 256), ("k32", 1024),
+                        ("k32", 2048)]
+
+
+def tjds_gather_matrix(t, index, tile):
+    """TjdsMatrix on the one-kernel product with the given stream form and tile size (0 = the plan's own choice)."""
+    old = os.environ.get("SMVP_TJDS_INDEX")
+    os.environ["SMVP_TJDS_INDEX"] = index
+    try:
+        T = sm.TjdsMatrix(t)
+    finally:
+        if old is None:
+            del os.environ["SMVP_TJDS_INDEX"]
+        else:
+            os.environ["SMVP_TJDS_INDEX"] = old
+    if tile:
+        T.set_tile(tile)
+    flavor = 3 if index == "sorted" else 2
+    name = T.describe()[0]
+    assert name.endswith(", %d>" % flavor), name
+    if tile:
+        assert name == "csr_stream_owner<%d, %d>" % (tile // 256, flavor), name
+    return T
+
+
 @pytest.mark.parametrize("name", SAMPLES)
-@pytest.mark.parametrize("mode", [sm.TJDS_MODE_TWO_PHASE, sm.TJDS_MODE_ATOMIC])
+@pytest.mark.parametrize("mode", TJDS_MODES)
 def test_tjds_sample_matrices(torch, name, mode):
     m, n, coo = load(name)
     t = sm.tjds_from_coo(coo, m, n)
     row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
     T = sm.TjdsMatrix(t)
+    assert T.describe()[0].startswith("csr_stream_owner<")     # the default is the one-kernel product
     T.set_mode(mode)
     assert ("products" in T.describe()[0]) == (mode == sm.TJDS_MODE_TWO_PHASE)
+    assert ("scatter" in T.describe()[0]) == (mode == sm.TJDS_MODE_ATOMIC)
     for x in (np.ones(n), np.random.default_rng(67890).random(n)):
         ref = ob.csr_spmv(row_ptr, col_ind, val, x)          # a correct TJDS computes A x
         dy = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
@@ -242,8 +271,28 @@ def test_csr_edge_cases(torch, case, kernel, param):
     assert_close(y, ref, row_scale(row_ptr, col_ind, val, x))
 
 
-def test_tjds_two_phase_is_bit_reproducible_and_needs_no_zeroing(torch):
-    """Products stored once, summed per row in a fixed order: identical bits run to run, y may hold garbage."""
+@pytest.mark.parametrize("name", SAMPLES)
+@pytest.mark.parametrize("index,tile", TJDS_GATHER_VARIANTS)
+def test_tjds_row_gather_variants_on_samples(torch, name, index, tile):
+    """Every stream form / tile size of the one-kernel TJDS product against the oracle's CSR and TJDS results."""
+    m, n, coo = load(name)
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    T = tjds_gather_matrix(sm.tjds_from_coo(coo, m, n), index, tile)
+    for x in (np.ones(n), np.random.default_rng(67890).random(n)):
+        dy = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+        T.set_x(dev(torch, x))
+        T.spmv(dy)
+        torch.cuda.synchronize()
+        y = dy.cpu().numpy()
+        scale = row_scale(row_ptr, col_ind, val, x)
+        assert_close(y, ob.csr_spmv(row_ptr, col_ind, val, x), scale, exact=(name in EXACT and x[0] == 1.0))
+        assert_close(y, ob.tjds_spmv(ob.tjds_build(coo, m, n), x), scale)
+    T.close()
+
+
+def test_tjds_products_are_bit_reproducible_and_need_no_zeroing(torch):
+    """The one-kernel and the two-phase product sum each row's products in one fixed order (ascending TJDS position):
+    identical bits run to run, between the two forms and between tile sizes; y may hold garbage on entry."""
     m, n, coo = load("memplus.mtx")
     T = sm.TjdsMatrix(sm.tjds_from_coo(coo, m, n))
     T.set_x(dev(torch, np.random.default_rng(2).random(n)))
@@ -255,6 +304,15 @@ def test_tjds_two_phase_is_bit_reproducible_and_needs_no_zeroing(torch):
         torch.cuda.synchronize()
         ys.append(dy.clone())
     assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    for mode, tile in ((sm.TJDS_MODE_TWO_PHASE, 0), (sm.TJDS_MODE_ROW_GATHER, 1024), (sm.TJDS_MODE_ROW_GATHER, 2048)):
+        T.set_mode(mode)
+        if tile:
+            T.set_tile(tile)
+        dy = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+        T.spmv(dy)
+        torch.cuda.synchronize()
+        assert torch.equal(dy, ys[0]), (mode, tile)
+    T.set_mode(sm.TJDS_MODE_ROW_GATHER)
     # the same through device-built arrays
     d_coo = torch.from_numpy(np.ascontiguousarray(coo).view(np.uint8).copy()).cuda()
     T2 = sm.TjdsMatrix(sm.tjds_from_coo_device(d_coo, m, n, len(coo)))
@@ -265,7 +323,25 @@ def test_tjds_two_phase_is_bit_reproducible_and_needs_no_zeroing(torch):
     assert torch.equal(dy, ys[0])
 
 
-@pytest.mark.parametrize("mode", [sm.TJDS_MODE_TWO_PHASE, sm.TJDS_MODE_ATOMIC])
+@pytest.mark.parametrize("index,tile", TJDS_GATHER_VARIANTS)
+@pytest.mark.parametrize("case", sorted(EDGE_CASES))
+def test_tjds_row_gather_edge_cases(torch, case, index, tile):
+    rng = np.random.default_rng(zlib.crc32(case.encode()))
+    lens, cols = EDGE_CASES[case](rng)
+    row_ptr, col_ind, val = csr_from_lengths(rng, lens, cols)
+    rows = len(lens)
+    coo = sm.make_coo(np.repeat(np.arange(rows), lens), col_ind, val)
+    x = rng.random(cols)
+    T = tjds_gather_matrix(sm.tjds_from_coo(coo, rows, cols), index, tile)
+    T.set_x(dev(torch, x))
+    dy = torch.full((max(rows, 1),), float("nan"), dtype=torch.float64, device="cuda")
+    T.spmv(dy)
+    torch.cuda.synchronize()
+    assert_close(dy.cpu().numpy()[:rows], ob.csr_spmv(row_ptr, col_ind, val, x), row_scale(row_ptr, col_ind, val, x))
+    T.close()
+
+
+@pytest.mark.parametrize("mode", TJDS_MODES)
 @pytest.mark.parametrize("case", sorted(EDGE_CASES))
 def test_tjds_edge_cases_handles(torch, case, mode):
     rng = np.random.default_rng(zlib.crc32(case.encode()))
@@ -679,7 +755,7 @@ def test_bench_script_tjds_format(torch):
                        capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
     j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
-    assert j["config"]["format"] == "tjds" and "TJDS" in j["metric"] and "products" in j["roofline"]["kernel"]
+    assert j["config"]["format"] == "tjds" and "TJDS" in j["metric"] and j["roofline"]["kernel"] == "csr_stream_owner<8, 3>"
     assert j["extra"]["full_size_parity"]["y_equals_tiled_reference_memplus_y"] and j["value"] > 0
 
 
@@ -777,9 +853,11 @@ def test_fuzz_all_kernels_against_oracle(torch, seed):
     assert np.array_equal(y[lens <= 32], ref[lens <= 32])          # short rows: the serial loop's bits
     coo = sm.make_coo(np.repeat(np.arange(rows), lens), col_ind, val)
     coo = coo[np.random.default_rng(seed).permutation(len(coo))]
-    for mode in (sm.TJDS_MODE_TWO_PHASE, sm.TJDS_MODE_ATOMIC):
+    for mode in TJDS_MODES:
         T = sm.TjdsMatrix(sm.tjds_from_coo(coo, rows, cols))
         T.set_mode(mode)
+        if mode == sm.TJDS_MODE_ROW_GATHER:
+            T.set_tile((256, 1024, 2048)[seed % 3])
         T.set_x(dev(torch, x))
         dy = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
         T.zero_y(dy)
@@ -793,14 +871,44 @@ def test_fuzz_all_kernels_against_oracle(torch, seed):
     assert np.array_equal(rp.cpu().numpy(), row_ptr) and np.array_equal(ci.cpu().numpy(), col_ind)
 
 
-def test_many_iterations_use_the_event_ring(torch):
-    """-n beyond the ring of 1024 event pairs: every product still gets its own time."""
+@pytest.mark.parametrize("timing", [sm.TIMING_EVENTS, sm.TIMING_DEVICE])
+def test_many_iterations_use_the_timing_rings(torch, timing):
+    """-n beyond the ring of 1024 event pairs / 256 stamped products per graph replay: every product still gets its own time."""
     m, n, coo = load("ibm32.mtx")
-    y, ms, st = sm.csr_compute(coo, m, n, iters=2500)
+    y, ms, st = sm.csr_compute(coo, m, n, iters=2500, timing=timing)
     assert len(ms) == 2500 and np.all(ms > 0) and st.time_total == pytest.approx(ms.sum())
+    assert sm.last_run_info().timing == timing
     assert ob.fmt_g(y) == ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_1615284655.txt"))
-    y, ms, st = sm.tjds_compute(coo, m, n, iters=1025)
+    y, ms, st = sm.tjds_compute(coo, m, n, iters=1025, timing=timing)
     assert len(ms) == 1025 and np.all(ms > 0)
+    assert ob.fmt_g(y) == ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_1615284655.txt"))
+
+
+def test_device_timing_agrees_with_events_and_is_the_default_for_small_launches(torch):
+    """The reference's window holds the product only (main-cli.c:408-419).  On its own sample matrices the kernel times
+    itself (wall-clock stamps per wave, products replayed from a hipGraph); a hipEvent pair around the same launch
+    can only read longer (it includes the launch and the events), and never by more than a few launch overheads."""
+    m, n, coo = load("memplus.mtx")
+    for fn in (sm.csr_compute, sm.tjds_compute):
+        y_d, ms_d, st_d = fn(coo, m, n, iters=300)                       # AUTO -> device stamps for 493 workgroups
+        info = sm.last_run_info()
+        assert info.timing == sm.TIMING_DEVICE and info.graph_replays == 2 and info.device_clock_khz > 0
+        assert info.wall_ms >= st_d.time_total * 0.5
+        y_e, ms_e, st_e = fn(coo, m, n, iters=300, timing=sm.TIMING_EVENTS)
+        assert sm.last_run_info().timing == sm.TIMING_EVENTS
+        assert np.array_equal(y_d, y_e)
+        assert 0.0005 < st_d.time_min <= st_d.time_avg < 0.05           # microseconds, not garbage ticks
+        assert st_d.time_avg <= st_e.time_avg * 1.05 and st_e.time_avg - st_d.time_avg < 0.03
+    # a launch of more than 4096 workgroups keeps the event pair under AUTO
+    rng = np.random.default_rng(5)
+    rows = 2_500_000                                                            # 5 M entries = 4883 tiles of 1024
+    coo_big = sm.make_coo(np.repeat(np.arange(rows), 2), rng.integers(0, rows, 2 * rows), rng.random(2 * rows))
+    sm.csr_compute(coo_big, rows, rows, iters=3)
+    assert sm.last_run_info().timing == sm.TIMING_EVENTS
+    sm.csr_compute(coo_big, rows, rows, iters=3, timing=sm.TIMING_DEVICE)      # but can be asked for
+    assert sm.last_run_info().timing == sm.TIMING_DEVICE
+    with pytest.raises(sm.SmvpError):                                           # not with a changing operand
+        sm.csr_compute(coo, m, n, iters=3, iterate=True, timing=sm.TIMING_DEVICE)
 
 
 def test_config4_full_size_properties(torch):
