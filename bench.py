@@ -9,19 +9,24 @@ HBM, CSR, x = ones like the reference (main-cli.c:368-369).  memplus.mtx itself 
 1.9 MB and lives in L2, so it says nothing about HBM; the workloads are HBM-sized
 matrices with memplus's shape (DESIGN.md "Workloads" has the reasoning):
 
-  memplus_tiled   (default) memplus.mtx replicated 944x along the diagonal,
+  memplus_tiled   (default, the headline) memplus.mtx replicated 944x along the diagonal,
                   kron(I_944, memplus): 16.76 M rows, 119 M entries, 1.77 GB of
-                  algorithmic traffic.  Every structural property of memplus is kept
-                  exactly (row lengths, symmetry, its 165 hub rows/columns, all entries
+                  algorithmic traffic.  It is the EXACT-STRUCTURE SUBSTITUTE for the random
+                  "memplus-shaped" model of SURVEY 8(d): every structural property of memplus
+                  is kept exactly (row lengths, symmetry, its 165 hub rows/columns, all entries
                   within 17757 of the diagonal) and y is checkable at full size against
                   the reference's own committed memplus report.
-  memplus_shaped  the random model of SURVEY 8(d): memplus's row-length histogram
+  memplus_shaped  the random model of SURVEY 8(d) itself: memplus's row-length histogram
                   and band profile, entries beyond distance 4096 uniform over ALL 2^24
                   columns.  Always measured too (extra.survey_random_model): it is bound
                   by the chip's random-gather rate, not by HBM.
-  uniform32       BASELINE config 4: 10 M x 10 M, 32 uniform entries per row.
+  uniform32       BASELINE config 4: 10 M x 10 M, 32 uniform entries per row.  Measured at
+                  EVERY N (extra.config4): the 1 -> 8 GPU curve of BASELINE.md section 4 is
+                  written on this matrix -- local products alone, products + all-gather of y,
+                  and the chunked form that sends chunk c while chunk c+1 is multiplied.
+  pwt_tiled       pwt.mtx x459 (extra.pwt_tiled, N = 1).
 
-With N > 1 the fixed matrix is cut into N row blocks, one process per GPU, and a
+With N > 1 the headline matrix is cut into N row blocks, one process per GPU, and a
 step is the local product plus the RCCL all-gather of the y blocks over xGMI
 (strong scaling).
 
@@ -63,6 +68,9 @@ def parse():
     ap.add_argument("--no-tjds", action="store_true", help="skip the TJDS leg (extra.tjds)")
     ap.add_argument("--no-random-model", action="store_true", help="skip extra.survey_random_model")
     ap.add_argument("--no-samples", action="store_true", help="skip extra.sample_matrices (BASELINE configs 2, 3, 5)")
+    ap.add_argument("--no-config4", action="store_true", help="skip extra.config4 (10 M x 32/row, every N)")
+    ap.add_argument("--no-pwt-tiled", action="store_true", help="skip extra.pwt_tiled (N = 1)")
+    ap.add_argument("--chunks", type=int, default=4, help="config 4, N > 1: row chunks per rank for the overlapped all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0, help="0 = sized for about 15 s")
     ap.add_argument("--no-allgather", action="store_true", help="N > 1: time the local products only")
@@ -140,7 +148,8 @@ def build_block(sm, sharding, workload, args, rank, world):
         row_ptr, col_ind, val = sharding.tile_block_diagonal(rp, ci, v, n, c0, c1)
         blk = dict(rows_total=m * copies, cols_total=n * copies, r0=m * c0, r1=m * c1,
                    bounds=np.array([m * (copies * g // world) for g in range(world + 1)], dtype=np.int64),
-                   name="memplus.mtx x%d block-diagonal (kron(I_%d, memplus))" % (copies, copies),
+                   name="memplus.mtx x%d block-diagonal (kron(I_%d, memplus)) -- the exact-structure substitute for the "
+                        "SURVEY 8(d) random memplus-shaped model, which is in extra.survey_random_model" % (copies, copies),
                    base=(m, n, rp, ci, v, c1 - c0))
     else:
         if workload == "memplus_shaped":
@@ -273,6 +282,150 @@ def measure_csr(torch, dist, sm, sharding_mod, blk, args, world, local_rank, ran
     return res
 
 
+def measure_config4(torch, dist, sm, sharding_mod, args, world, local_rank, rank, steps):
+    """BASELINE config 4 (10 M x 10 M, 32 uniform entries per row, seed 2024) on `world` GPUs -> dict for extra.config4.
+
+    Row ownership is block-cyclic (sharding.cyclic_chunk_rows): every rank holds `chunks` row chunks, each its own CSR
+    handle; the all-gather of chunk c lands as one contiguous run of the full y.  Three timings, all max over ranks:
+    local products only; products, then the all-gathers (nothing overlapped); each chunk's all-gather issued
+    asynchronously behind its product (chunk c travels while chunk c+1 is multiplied).
+    """
+    rows = args.rows
+    chunks = max(1, args.chunks) if world > 1 else 1
+    t0 = time.perf_counter()
+    ex = sharding_mod.ChunkedExchange(torch, dist, rows, world, rank, chunks, "cuda")
+    threads = max(1, min(64, (os.cpu_count() or 8) // max(1, world)))
+    mats, nnz_local, alg_local, checks = [], 0, 0.0, []
+    for c, (r0, r1) in enumerate(ex.ranges):
+        rp, ci, v = sm.synth_csr(sm.SYNTH_UNIFORM, 2024, rows, rows, 32, r0, r1, threads=threads)
+        A = sm.CsrMatrix(r1 - r0, rows, torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(v).cuda(),
+                         device=local_rank)
+        n = int(rp[-1])
+        nnz_local += n
+        alg_local += A.describe()[1]
+        # x = ones (the reference's operand): y = the row sums of val, computed independently on the host
+        host = np.add.reduceat(v, rp[:-1]) if n else np.zeros(r1 - r0)
+        scale = np.add.reduceat(np.abs(v), rp[:-1]) if n else np.zeros(r1 - r0)
+        checks.append((r0, r1, host, scale))
+        mats.append(A)
+        del rp, ci, v
+    kname = mats[0].describe()[0]
+    log(rank, "config 4: rows %d, %d chunk(s) per rank, %d local entries, built in %.1f s" % (rows, chunks, nnz_local,
+                                                                                             time.perf_counter() - t0))
+    d_x = torch.ones(rows, dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream()
+
+    def product(c, out):
+        r0, r1 = ex.ranges[c]
+        if r1 > r0:
+            mats[c].spmv(d_x, out, stream=stream)
+
+    gather = world > 1 or dist.is_initialized()
+    y_full = ex.step(product, overlap=True, gather=gather)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for c, (r0, r1, host, scale) in enumerate(checks):
+        got = ex.local(c)[:r1 - r0].cpu().numpy()
+        err = np.abs(got - host)
+        if not np.all(err <= TOL * scale):
+            raise SystemExit("rank %d: config 4 chunk %d is wrong" % (rank, c))
+        worst = max(worst, float((err / np.maximum(scale, 1e-300)).max()) if len(err) else 0.0)
+        if gather and not np.array_equal(y_full[r0:r1].cpu().numpy(), got):
+            raise SystemExit("rank %d: the gathered y does not hold this rank's chunk %d" % (rank, c))
+    if gather:   # every rank must hold the same full vector
+        chk = float(y_full.sum().item())
+        t = torch.tensor([chk, -chk], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if float(t[0]) != -float(t[1]):
+            raise SystemExit("config 4: all-gathered y differs between ranks")
+    del checks
+
+    def run(overlap, do_gather):
+        for _ in range(2):
+            ex.step(product, overlap=overlap, gather=do_gather)
+        wall, ev = timed_region(torch, dist, world, steps, lambda: ex.step(product, overlap=overlap, gather=do_gather))
+        return wall / steps * 1e3, ev / steps
+
+    _, spmv_ms = run(False, False)
+    tot = torch.tensor([nnz_local, alg_local], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tot)
+    nnz, alg = float(tot[0]), float(tot[1])
+    out = {"workload": "uniform 32 entries/row rows=%d seed=2024 (BASELINE config 4)" % rows, "rows": rows, "nnz": int(nnz),
+           "n_gpus": world, "kernel": kname, "chunks_per_rank": chunks, "steps": steps,
+           "spmv_only_ms": round(spmv_ms, 4), "spmv_only_GFLOPs": round(2.0 * nnz / spmv_ms * 1e-6, 1),
+           "max_normwise_error_vs_host": worst,
+           "x_gathers_per_second_G": round(nnz / spmv_ms * 1e-6 / world, 1),
+           "note": "every x gather of this matrix misses L2 (uniform columns over an 80 MB x): one GPU is bound by its "
+                   "L2-miss gather rate (about 54 G/s, tools/gather_bench.hip), not by HBM bytes"}
+    if world == 1:
+        out["frac_of_hbm_peak"] = round(alg / spmv_ms * 1e-6 / HBM_PEAK_GBS, 4)
+        out["achieved_GBps"] = round(alg / spmv_ms * 1e-6, 1)
+    if gather:
+        plain_ms, _ = run(False, True)
+        over_ms, _ = run(True, True)
+        out.update(step_ms_products_then_allgather=round(plain_ms, 4), step_ms_overlapped=round(over_ms, 4),
+                   step_GFLOPs_products_then_allgather=round(2.0 * nnz / plain_ms * 1e-6, 1),
+                   step_GFLOPs_overlapped=round(2.0 * nnz / over_ms * 1e-6, 1), y_bytes_gathered=rows * 8,
+                   exchange="block-cyclic row chunks, one all_gather_into_tensor per chunk (%s)" %
+                            os.environ.get("SMVP_DIST_BACKEND", "nccl = RCCL over xGMI"))
+    for A in mats:
+        A.close()
+    return out
+
+
+def measure_pwt_tiled(torch, dist, sm, sharding_mod, local_rank, rank, steps):
+    """pwt.mtx replicated 459x along the diagonal (16.76 M rows, 83 M stored entries): CSR and TJDS -> extra.pwt_tiled."""
+    tc, m, n, coo = sm.mm_read_coo(golden_file("sample-data", "pwt.mtx"))
+    rp, ci, v = sm.csr_from_coo(coo, m)
+    copies = 459
+    RP, CI, V = sharding_mod.tile_block_diagonal(rp, ci, v, n, 0, copies)
+    rows, cols, nnz = m * copies, n * copies, int(RP[-1])
+    A = sm.CsrMatrix(rows, cols, torch.from_numpy(RP).cuda(), torch.from_numpy(CI).cuda(), torch.from_numpy(V).cuda(), device=local_rank)
+    kname, alg = A.describe()
+    d_x = torch.ones(cols, dtype=torch.float64, device="cuda")
+    d_y = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream()
+    A.spmv(d_x, d_y, stream=stream)
+    torch.cuda.synchronize()
+    # pattern matrix, x = ones: y = tile(row lengths of pwt) exactly, which is also what the reference's committed
+    # report output-test/smvp-toolbox_report_CSR_1615284671.txt prints
+    want = report_y_lines("smvp-toolbox_report_CSR_1615284671.txt")
+    y = d_y.cpu().numpy().reshape(copies, m)
+    if not (np.array_equal(y[0], np.diff(rp).astype(np.float64)) and np.array_equal(y, np.tile(y[0], (copies, 1)))
+            and all(("%g" % a) == b for a, b in zip(y[0], want))):
+        raise SystemExit("pwt x%d: y is not tile(y_pwt of the committed report)" % copies)
+    for _ in range(3):
+        A.spmv(d_x, d_y, stream=stream)
+    _, ms = timed_region(torch, dist, 1, steps, lambda: A.spmv(d_x, d_y, stream=stream))
+    ms /= steps
+    out = {"workload": "pwt.mtx x%d block-diagonal (kron(I_%d, pwt), stored triangle only like the reference)" % (copies, copies),
+           "rows": rows, "nnz": nnz, "kernel": kname, "ms_per_launch": round(ms, 5), "GFLOPs": round(2.0 * nnz / ms * 1e-6, 1),
+           "achieved_GBps": round(alg / ms * 1e-6, 1), "frac_of_hbm_peak": round(alg / ms * 1e-6 / HBM_PEAK_GBS, 4),
+           "y_equals_tiled_reference_pwt_y": True}
+    A.close()
+    coo2 = np.zeros(nnz, dtype=sm.COO_DTYPE)
+    coo2["row"] = np.repeat(np.arange(rows, dtype=np.int32), np.diff(RP))
+    coo2["col"], coo2["val"] = CI, V
+    d_coo = torch.from_numpy(coo2.view(np.uint8)).cuda()
+    del coo2, RP, CI, V
+    T = sm.TjdsMatrix(sm.tjds_from_coo_device(d_coo, rows, cols, nnz), device=local_rank)
+    del d_coo
+    T.set_x(d_x, stream=stream)
+    d_yt = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+    T.spmv(d_yt, stream=stream)
+    torch.cuda.synchronize()
+    if not torch.equal(d_yt, d_y):
+        raise SystemExit("pwt x%d: TJDS differs from CSR" % copies)
+    tname, tbytes = T.describe()
+    _, tms = timed_region(torch, dist, 1, steps, lambda: T.spmv(d_yt, stream=stream))
+    tms /= steps
+    out["tjds"] = {"kernel": tname, "ms_per_step": round(tms, 5), "GFLOPs": round(2.0 * nnz / tms * 1e-6, 1),
+                   "frac_of_hbm_peak": round(tbytes / tms * 1e-6 / HBM_PEAK_GBS, 4), "equals_csr_bit_for_bit": True}
+    T.close()
+    return out
+
+
 def recorded_traffic(workload, kernel, alg_bytes):
     """HBM bytes per launch from the committed PMC passes (profiles/*traffic.json), if one matches this run.
 
@@ -299,7 +452,7 @@ def roofline_of(res, workload=None):
     r = {"bound": "hbm", "kernel": res["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
          "alg_bytes_per_launch": res["alg_bytes_local"], "ms_per_launch": round(res["kernel_ms"], 5),
-         "note": "per product (CSR: one launch; TJDS: products kernel + row sums), HIP events on the launch stream"}
+         "note": "one launch per product (CSR and TJDS alike), HIP events on the launch stream"}
     rec = recorded_traffic(workload, res["kernel"], res["alg_bytes_local"]) if workload else None
     if rec:
         r["traffic"] = rec[0]
@@ -374,7 +527,7 @@ def main():
             T.set_x(res["d_x"], stream=stream)
 
             def tjds_step():
-                T.zero_y(d_yt, stream=stream)       # a no-op for the two-phase product (it overwrites y)
+                T.zero_y(d_yt, stream=stream)       # a no-op unless the atomic form is selected
                 T.spmv(d_yt, stream=stream)
 
             tjds_step()
@@ -382,24 +535,32 @@ def main():
             terr = float((np.abs(d_yt.cpu().numpy() - res["got"]) / np.maximum(res["scale"], 1e-300)).max())
             if terr > TOL:
                 raise RuntimeError("TJDS differs from CSR: %g" % terr)
-            tsteps = max(5, args.steps // 10)
+            tsteps = max(5, args.steps // 4)
             _, t_ms = timed_region(torch, dist, 1, tsteps, tjds_step)
             t_ms /= tsteps
+            tj_workload = blk["name"] + ", TJDS, x=%s" % args.x
+            trec = recorded_traffic(tj_workload, tname, tbytes)
             extra["tjds"] = {"kernel": tname, "ms_per_step": round(t_ms, 4), "num_diag": tj.num_diag,
                              "GFLOPs": round(2.0 * blk["nnz"] / (t_ms * 1e-3) * 1e-9, 1),
                              "achieved_GBps": round(tbytes / (t_ms * 1e-3) * 1e-9, 1),
                              "frac_of_hbm_peak": round(tbytes / (t_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4),
                              "max_normwise_diff_vs_csr": terr, "steps": tsteps,
-                             "note": "step = column-major products kernel + per-row sum through the row-inverted index "
-                                     "(no atomics, bit-reproducible); extra.tjds_atomic is the one-pass atomic form"}
-            T.set_mode(sm.TJDS_MODE_ATOMIC)
-            tjds_step()
-            _, a_ms = timed_region(torch, dist, 1, tsteps, tjds_step)
-            a_ms /= tsteps
-            extra["tjds_atomic"] = {"kernel": T.describe()[0], "ms_per_step": round(a_ms, 4),
-                                    "GFLOPs": round(2.0 * blk["nnz"] / (a_ms * 1e-3) * 1e-9, 1),
-                                    "frac_of_hbm_peak": round(tbytes / (a_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4),
-                                    "note": "memset(y) + scatter with fp64 atomics"}
+                             "traffic_bytes_per_product": trec[0] if trec else None,
+                             "traffic_source": ("profiles/" + trec[1]) if trec else None,
+                             "note": "ONE kernel per product: the entries regrouped by row at create time (val / row_ind / "
+                                     "start_pos / perm untouched), every 2048-entry tile walks its piece of the jagged "
+                                     "diagonals in TJDS order, products meet in LDS, one lane (or wave) per row sums them; "
+                                     "no atomics, bit-reproducible.  extra.tjds_two_phase / tjds_atomic are the older forms"}
+            for key, mode in (("tjds_two_phase", sm.TJDS_MODE_TWO_PHASE), ("tjds_atomic", sm.TJDS_MODE_ATOMIC)):
+                T.set_mode(mode)
+                tjds_step()
+                _, a_ms = timed_region(torch, dist, 1, max(3, tsteps // 2), tjds_step)
+                a_ms /= max(3, tsteps // 2)
+                extra[key] = {"kernel": T.describe()[0], "ms_per_step": round(a_ms, 4),
+                              "GFLOPs": round(2.0 * blk["nnz"] / (a_ms * 1e-3) * 1e-9, 1),
+                              "frac_of_hbm_peak": round(tbytes / (a_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4)}
+            extra["tjds_two_phase"]["note"] = "column-major products kernel + per-row sums through the row-inverted index"
+            extra["tjds_atomic"]["note"] = "memset(y) + column-major scatter with fp64 atomics"
             T.close()
             del T, tj, d_yt
         except Exception as e:  # the TJDS leg is informational; never lose the headline line over it
@@ -438,12 +599,22 @@ def main():
             try:
                 tc, m, n, coo = sm.mm_read_coo(golden_file("sample-data", name))
                 y_c, ms_c, st_c = sm.csr_compute(coo, m, n, iters=1000, device=local_rank)
+                info_c = sm.last_run_info()
                 y_t, ms_t, st_t = sm.tjds_compute(coo, m, n, iters=1000, device=local_rank)
+                info_t = sm.last_run_info()
+                _, _, ev_c = sm.csr_compute(coo, m, n, iters=1000, device=local_rank, timing=sm.TIMING_EVENTS)
+                _, _, ev_t = sm.tjds_compute(coo, m, n, iters=1000, device=local_rank, timing=sm.TIMING_EVENTS)
                 e = {"rows": m, "nnz": len(coo), "iters": 1000,
+                     "timing": "per product on the device: every wave stamps the constant-rate wall clock when it starts "
+                               "and when its last store is acknowledged, time = max(last) - min(first); the 1000 "
+                               "products are replayed from a hipGraph" if info_c.timing == sm.TIMING_DEVICE else "hipEvent pairs",
                      "csr_avg_ms": round(st_c.time_avg, 6), "csr_min_ms": round(st_c.time_min, 6),
                      "csr_GFLOPs": round(2.0 * len(coo) / st_c.time_avg * 1e-6, 2),
+                     "csr_loop_wall_ms_per_product": round(info_c.wall_ms / 1000.0, 6),
                      "tjds_avg_ms": round(st_t.time_avg, 6), "tjds_min_ms": round(st_t.time_min, 6),
-                     "tjds_GFLOPs": round(2.0 * len(coo) / st_t.time_avg * 1e-6, 2)}
+                     "tjds_GFLOPs": round(2.0 * len(coo) / st_t.time_avg * 1e-6, 2),
+                     "tjds_loop_wall_ms_per_product": round(info_t.wall_ms / 1000.0, 6),
+                     "csr_avg_ms_event_pairs": round(ev_c.time_avg, 6), "tjds_avg_ms_event_pairs": round(ev_t.time_avg, 6)}
                 if not args.no_cpu_baseline:
                     import oracle_binding as ob      # CPU baseline leg: the serial loops on this host, 1 thread
 
@@ -470,6 +641,24 @@ def main():
     del res["keep"], res["d_x"], res["d_y"]
     torch.cuda.empty_cache()
 
+    # ------------------------------------------------------------ BASELINE config 4 at this N; pwt x459 at N = 1
+    if not args.no_config4:
+        try:
+            extra["config4"] = measure_config4(torch, dist, sm, sharding, args, world, local_rank, rank, max(5, args.steps // 4))
+        except SystemExit:
+            raise
+        except Exception as e:
+            extra["config4"] = {"error": str(e)}
+        torch.cuda.empty_cache()
+    if world == 1 and not args.no_pwt_tiled:
+        try:
+            extra["pwt_tiled"] = measure_pwt_tiled(torch, dist, sm, sharding, local_rank, rank, max(10, args.steps // 2))
+        except SystemExit:
+            raise
+        except Exception as e:
+            extra["pwt_tiled"] = {"error": str(e)}
+        torch.cuda.empty_cache()
+
     # ------------------------------------------------------------ the survey's random model, for the record
     if args.workload == "memplus_tiled" and not args.no_random_model and world == 1:
         try:
@@ -482,6 +671,9 @@ def main():
                 "GFLOPs": round(2.0 * blk2["nnz"] / (r2["kernel_ms"] * 1e-3) * 1e-9, 1),
                 "achieved_GBps": rl["achieved"], "frac_of_hbm_peak": rl["frac"],
                 "share_of_entries_beyond_4096": round(far, 3),
+                "traffic_over_algorithmic": 4.5,
+                "traffic_source": "profiles/r01_random_model_pmc_summary.txt: FETCH_SIZE 3 789 424 KB x2 + writes = 7.9 GB moved "
+                                  "for 1.77 GB algorithmic",
                 "note": "uniformly random far columns: bound by the measured L2-miss gather rate (~54 G gathers/s, "
                         "tools/gather_bench.hip), not by HBM bytes"}
             r2["A"].close()

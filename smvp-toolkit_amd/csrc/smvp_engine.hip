@@ -428,7 +428,7 @@ extern "C" int smvp_csr_describe(const smvp_csr_t *h, char *kernel_name, size_t 
         if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
             snprintf(kernel_name, cap, "csr_vector_rows<%d>", h->lanes_per_row);
         else if (h->kernel == SMVP_CSR_KERNEL_STREAM)
-            snprintf(kernel_name, cap, "csr_stream_owner<%d, %d>", h->vpt, h->flavor);
+            snprintf(kernel_name, cap, "csr_stream_owner<%d, %d, false>", h->vpt, h->flavor);
         else
             snprintf(kernel_name, cap, "csr_stream_tiles<%d>", h->vpt);
     }
@@ -777,10 +777,10 @@ extern "C" int smvp_tjds_describe(const smvp_tjds_t *h, char *kernel_name, size_
         if (h->quirks || h->mode == SMVP_TJDS_MODE_ATOMIC)
             snprintf(kernel_name, cap, "tjds_colmajor_scatter<%s>", h->quirks ? "true" : "false");
         else if (h->mode == SMVP_TJDS_MODE_TWO_PHASE)
-            snprintf(kernel_name, cap, "tjds_colmajor_products + csr_stream_owner<%d, %d>", h->inv ? h->inv->vpt : 0,
+            snprintf(kernel_name, cap, "tjds_colmajor_products + csr_stream_owner<%d, %d, false>", h->inv ? h->inv->vpt : 0,
                      smvp::kFlavorUnit);
         else
-            snprintf(kernel_name, cap, "csr_stream_owner<%d, %d>", h->rg ? h->rg->vpt : 0, h->rg ? h->rg->flavor : 0);
+            snprintf(kernel_name, cap, "csr_stream_owner<%d, %d, false>", h->rg ? h->rg->vpt : 0, h->rg ? h->rg->flavor : 0);
     }
     if (alg_bytes)
         *alg_bytes = 12.0 * h->planned_nnz + 4.0 * (h->num_diag + 1.0) + 8.0 * h->cols + 8.0 * h->rows;

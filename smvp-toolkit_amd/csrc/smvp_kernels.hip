@@ -211,22 +211,27 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_tiles(
 // ---------------------------------------------------------------------------
 typedef int int4v __attribute__((ext_vector_type(4)));               // clang vectors: what the non-temporal builtins take
 
-struct OwnerArgs {
-    const int *row_ptr;       // rows + 1 segment bounds over the entry stream
-    const int *col_ind;       // Csr/Unit: column; TjdsK: permuted column k
-    const double *val;        // Csr: values in stream order; Tjds*: the TJDS val array (gathered through pos)
-    const double *x;          // operand (Tjds*: x_perm)
-    double *y;
-    const int *tile_row;
-    const int *tile_next;
+// The streams every flavour reads are plain __restrict__ kernel parameters (the compiler then keeps the uniform plan
+// reads on the scalar unit and is free to order the loads); what only some flavours need travels in this struct.
+struct OwnerExtra {
     const int *pos;                 // Tjds*: TJDS position of each stream entry
     const int *start_pos;           // TjdsS
-    unsigned long long *stamps;     // optional: per-wave {first, last} wall-clock ticks of this launch
-    int rows, nnz, ntiles, tile_group;
-    int stream_nt;                  // Tjds*: load the pos / diag / col_ind streams non-temporally (read once; keeps L2 for the gathers)
     const int *ovf_ptr;             // TjdsS: ntiles + 1 bounds of the tiles' overflow entries in ovf_pos / ovf_k
     const int *ovf_pos;             // TjdsS: TJDS position ...
     const int *ovf_k;               // TjdsS: ... and permuted column of the entries [e, tile_next) of each tile, row order
+    unsigned long long *stamps;     // STAMPED: per-wave {first, last} wall-clock ticks of this launch
+    int stream_nt;                  // TjdsS: load the pos / slot streams non-temporally (development switch)
+};
+
+// what the helpers below need of the kernel's arguments
+struct OwnerArgs {
+    const int *__restrict__ col_ind;
+    const double *__restrict__ val;
+    const double *__restrict__ x;
+    const int *__restrict__ pos;
+    const int *__restrict__ start_pos;
+    const int *__restrict__ ovf_pos;
+    const int *__restrict__ ovf_k;
 };
 
 // one entry's product the slow way (tile tails, overflow beyond one block width, giant rows)
@@ -255,9 +260,13 @@ __device__ __forceinline__ double owner_overflow_product(const OwnerArgs &a, int
         return owner_product_slow<FLAVOR>(a, (long long)e + i);
 }
 
-template <int VPT, int FLAVOR>
-__global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(const OwnerArgs a)
+template <int VPT, int FLAVOR, bool STAMPED>
+__global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
+    const int *__restrict__ row_ptr, const int *__restrict__ col_ind, const double *__restrict__ val,
+    const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ tile_row,
+    const int *__restrict__ tile_next, int rows, int nnz_arg, int ntiles, int tile_group_arg, const OwnerExtra ex)
 {
+    const OwnerArgs a = {col_ind, val, x, ex.pos, ex.start_pos, ex.ovf_pos, ex.ovf_k};
     constexpr int TILE = kStreamBlock * VPT;
     constexpr int QCAP = (TILE + kStreamOver) / kLongRow + 1;
     constexpr bool TJDS = FLAVOR == kFlavorTjdsK || FLAVOR == kFlavorTjdsS;
@@ -274,12 +283,15 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(const OwnerArgs
     // optional device-side timing: every wave notes when it started and (after its last store has been
     // acknowledged) when it finished; max(last) - min(first) over the launch is the product's own duration,
     // free of launch and event overhead (the engine reduces the slots, see stamp_reduce)
-    unsigned long long *const stamp = a.stamps ? a.stamps + 2 * ((size_t)blockIdx.x * (kStreamBlock / 64) + (t >> 6)) : nullptr;
-    if (stamp && (t & 63) == 0)
-        stamp[0] = wall_clock64();
+    unsigned long long *stamp = nullptr;
+    if constexpr (STAMPED) {
+        stamp = ex.stamps + 2 * ((size_t)blockIdx.x * (kStreamBlock / 64) + (t >> 6));
+        if ((t & 63) == 0)
+            stamp[0] = wall_clock64();
+    }
 #define SMVP_OWNER_EXIT()                                         \
     do {                                                          \
-        if (stamp) {                                              \
+        if constexpr (STAMPED) {                                  \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      \
             if ((t & 63) == 0)                                    \
                 stamp[1] = wall_clock64();                        \
@@ -287,10 +299,10 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(const OwnerArgs
         return;                                                   \
     } while (0)
 
-    const int b = tile_of_block(blockIdx.x, a.tile_group);
-    if (b >= a.ntiles)
+    const int b = tile_of_block(blockIdx.x, tile_group_arg);
+    if (b >= ntiles)
         SMVP_OWNER_EXIT();
-    const int nnz = a.nnz;
+    const int nnz = nnz_arg;
     const long long s = (long long)b * TILE;
     const long long j0 = s + (long long)t * VPT;
 
@@ -307,7 +319,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(const OwnerArgs
         if (full_tile) {
 #pragma unroll
             for (int k = 0; k < VPT; ++k) {
-                if (a.stream_nt) {
+                if (ex.stream_nt) {
                     pj[k] = __builtin_nontemporal_load(a.pos + s + k * kStreamBlock + t);
                     c[k] = __builtin_nontemporal_load(a.col_ind + s + k * kStreamBlock + t);
                 } else {
@@ -322,7 +334,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(const OwnerArgs
             for (int k = 0; k < VPT; k += 4)
                 *reinterpret_cast<int4 *>(&c[k]) = *reinterpret_cast<const int4 *>(a.col_ind + j0 + k);
             if constexpr (TJDS) {
-                if (a.stream_nt) {
+                if (ex.stream_nt) {
 #pragma unroll
                     for (int k = 0; k < VPT; k += 4)
                         *reinterpret_cast<int4v *>(&pj[k]) = __builtin_nontemporal_load(reinterpret_cast<const int4v *>(a.pos + j0 + k));
@@ -345,13 +357,13 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(const OwnerArgs
                 v[0] = a.val[j0];
         }
     }
-    const int rlo = a.tile_row[b];
-    const int rhi = a.tile_row[b + 1];
+    const int rlo = tile_row[b];
+    const int rhi = tile_row[b + 1];
     if (rlo == rhi)
         SMVP_OWNER_EXIT();  // all of this tile continues a row owned by an earlier tile
     const int lo = (int)s;  // nnz < 2^31
     const int e = (int)(s + TILE < (long long)nnz ? s + TILE : (long long)nnz);
-    const int zend = a.tile_next[b];  // row_ptr[rhi]: end of the last owned row, >= e
+    const int zend = tile_next[b];  // row_ptr[rhi]: end of the last owned row, >= e
     const int ext = zend - e;
     const bool giant = ext > kStreamOver;
     if (t == 0)
@@ -362,11 +374,11 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(const OwnerArgs
     int rp_a = 0, rp_b = 0;
     int ovf_base = 0;
     if constexpr (SORTED)
-        ovf_base = a.ovf_ptr[b];
+        ovf_base = ex.ovf_ptr[b];
     if constexpr (SORTED) {
         if (full_tile && rlo + t < rhi) {
-            rp_a = a.row_ptr[rlo + t];
-            rp_b = a.row_ptr[rlo + t + 1];
+            rp_a = row_ptr[rlo + t];
+            rp_b = row_ptr[rlo + t + 1];
         }
         int co = 0, pjo = 0;
         if (over0) {
@@ -404,8 +416,8 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(const OwnerArgs
         }
     } else if (whole) {
         if (rlo + t < rhi) {  // this lane's first row in phase 2
-            rp_a = a.row_ptr[rlo + t];
-            rp_b = a.row_ptr[rlo + t + 1];
+            rp_a = row_ptr[rlo + t];
+            rp_b = row_ptr[rlo + t + 1];
         }
         int co = 0, pjo = 0;
         double vo = 0.0;
@@ -462,13 +474,13 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(const OwnerArgs
         if (giant && r == last)
             continue;
         const bool pre = full_tile && r == rlo + t;
-        const int ra = (pre ? rp_a : a.row_ptr[r]) - lo;
-        const int rz = (pre ? rp_b : a.row_ptr[r + 1]) - lo;
+        const int ra = (pre ? rp_a : row_ptr[r]) - lo;
+        const int rz = (pre ? rp_b : row_ptr[r + 1]) - lo;
         if (rz - ra <= kLongRow) {
             double acc = 0.0;
             for (int i = ra; i < rz; ++i)
                 acc += prod[i];
-            __builtin_nontemporal_store(acc, &a.y[r]);
+            __builtin_nontemporal_store(acc, &y[r]);
         } else {
             const int q = atomicAdd(&long_count, 1);
             long_rows[q] = r;
@@ -489,12 +501,12 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(const OwnerArgs
             acc += prod[i];
         acc = shfl_down_sum<64>(acc);
         if (lane == 0)
-            a.y[long_rows[q]] = acc;
+            y[long_rows[q]] = acc;
     }
 
     // ---- phase 2d: a last row that runs far past the tile: LDS part + the rest from global memory
     if (giant) {
-        const int ra = a.row_ptr[last];
+        const int ra = row_ptr[last];
         double acc = 0.0;
         for (int i = ra - lo + t; i < e - lo; i += kStreamBlock)
             acc += prod[i];
@@ -518,7 +530,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(const OwnerArgs
 #pragma unroll
             for (int w = 0; w < kStreamBlock / 64; ++w)
                 total += wave_sum[w];
-            a.y[last] = total;
+            y[last] = total;
         }
     }
     SMVP_OWNER_EXIT();
@@ -802,21 +814,23 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
         return hipSuccess;
     const int group = tile_group(l.ntiles, flavor_group(flavor));
     const dim3 grid(owner_grid(l.ntiles, group));
-    OwnerArgs a;
-    a.row_ptr = l.row_ptr, a.col_ind = l.col_ind, a.val = l.val, a.x = l.x, a.y = l.y;
-    a.tile_row = l.tile_row, a.tile_next = l.tile_next, a.pos = l.pos, a.start_pos = l.start_pos;
-    a.stamps = l.stamps;
-    a.rows = l.rows, a.nnz = l.nnz, a.ntiles = l.ntiles, a.tile_group = group;
     static const int nt = [] {
         const char *e = getenv("SMVP_TJDS_NT");  // development switch
         return e ? atoi(e) : 0;
     }();
-    a.stream_nt = nt;
-    a.ovf_ptr = l.ovf_ptr, a.ovf_pos = l.ovf_pos, a.ovf_k = l.ovf_k;
-#define SMVP_OWNER(V, F)                                                                             \
-    if (vpt == V && flavor == F) {                                                                   \
-        hipLaunchKernelGGL((csr_stream_owner<V, F>), grid, dim3(kStreamBlock), 0, stream, a);        \
-        return hipGetLastError();                                                                    \
+    OwnerExtra ex;
+    ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_pos = l.ovf_pos, ex.ovf_k = l.ovf_k;
+    ex.stamps = l.stamps, ex.stream_nt = nt;
+#define SMVP_OWNER_ST(V, F, S)                                                                                     \
+    hipLaunchKernelGGL((csr_stream_owner<V, F, S>), grid, dim3(kStreamBlock), 0, stream, l.row_ptr, l.col_ind, l.val, \
+                       l.x, l.y, l.tile_row, l.tile_next, l.rows, l.nnz, l.ntiles, group, ex)
+#define SMVP_OWNER(V, F)                  \
+    if (vpt == V && flavor == F) {        \
+        if (l.stamps)                     \
+            SMVP_OWNER_ST(V, F, true);    \
+        else                              \
+            SMVP_OWNER_ST(V, F, false);   \
+        return hipGetLastError();         \
     }
     SMVP_OWNER(1, kFlavorCsr)
     SMVP_OWNER(4, kFlavorCsr)
@@ -831,6 +845,7 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
     SMVP_OWNER(4, kFlavorTjdsS)
     SMVP_OWNER(8, kFlavorTjdsS)
 #undef SMVP_OWNER
+#undef SMVP_OWNER_ST
     return hipErrorInvalidValue;
 }
 

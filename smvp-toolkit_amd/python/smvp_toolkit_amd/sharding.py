@@ -71,3 +71,62 @@ def tile_block_diagonal(row_ptr, col_ind, val, cols, copy_begin, copy_end):
     if len(ci) and ci.max() >= 2 ** 31:
         raise ValueError("column index beyond 32 bits")
     return rp.astype(np.int32), ci.astype(np.int32), np.tile(val, n)
+
+
+# ------------------------------------------------------------------ chunked exchange (overlap of product and all-gather)
+def cyclic_chunk_rows(rows_total, world, chunks):
+    """Block-cyclic row ownership: chunk c of rank r is the global row range [(c*world + r)*h, +h), h = ceil(rows /
+    (world*chunks)), clipped to rows_total (the last ranges may be short or empty).
+
+    With this layout the all-gather of chunk c of every rank lands as ONE contiguous run of the full vector,
+    y_full[c*world*h : (c+1)*world*h], in natural row order: equal counts, no padding between ranks, no compaction --
+    and the gather of chunk c can travel while chunk c+1 is being multiplied.  chunks = 1 is the plain row-block
+    partition.  Returns (h, ranges) with ranges[r][c] = (row_begin, row_end).
+    """
+    h = max(1, -(-rows_total // (world * chunks)))
+    ranges = [[(min(rows_total, (c * world + r) * h), min(rows_total, (c * world + r + 1) * h)) for c in range(chunks)]
+              for r in range(world)]
+    return h, ranges
+
+
+class ChunkedExchange:
+    """y blocks of one rank under cyclic_chunk_rows and their all-gather, plain or overlapped with the products.
+
+    product(c, out) must enqueue chunk c's product into `out` (h elements; rows past the chunk's end are left
+    untouched = the zero padding).  step(overlap): for every chunk, product then all-gather of that chunk.
+    overlap=False waits for all products before the first gather starts (the un-overlapped form); overlap=True
+    issues each gather asynchronously right behind its product (on the backend's own stream), so chunk c travels
+    while chunk c+1 is computed; the caller's stream waits for all of them at the end.
+    """
+
+    def __init__(self, torch, dist, rows_total, world, rank, chunks, device, group=None):
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world, self.rank, self.chunks, self.rows_total = world, rank, chunks, rows_total
+        self.h, ranges = cyclic_chunk_rows(rows_total, world, chunks)
+        self.ranges = ranges[rank]
+        self.y_local = torch.zeros(chunks * self.h, dtype=torch.float64, device=device)
+        self.y_full = torch.zeros(world * chunks * self.h, dtype=torch.float64, device=device)   # padded past rows_total
+
+    def local(self, c):
+        return self.y_local[c * self.h:(c + 1) * self.h]
+
+    def _gather(self, c, async_op):
+        dst = self.y_full[c * self.world * self.h:(c + 1) * self.world * self.h]
+        if self.world == 1 and not (hasattr(self.dist, "is_initialized") and self.dist.is_initialized()):
+            dst.copy_(self.local(c))
+            return None
+        return self.dist.all_gather_into_tensor(dst, self.local(c), group=self.group, async_op=async_op)
+
+    def step(self, product, overlap, gather=True):
+        works = []
+        for c in range(self.chunks):
+            product(c, self.local(c))
+            if gather and overlap:
+                works.append(self._gather(c, True))
+        if gather and not overlap:
+            for c in range(self.chunks):
+                self._gather(c, False)
+        for w in works:
+            if w is not None:
+                w.wait()
+        return self.y_full[:self.rows_total]

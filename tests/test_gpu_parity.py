@@ -162,9 +162,9 @@ def tjds_gather_matrix(t, index, tile):
         T.set_tile(tile)
     flavor = 3 if index == "sorted" else 2
     name = T.describe()[0]
-    assert name.endswith(", %d>" % flavor), name
+    assert name.endswith(", %d, false>" % flavor), name
     if tile:
-        assert name == "csr_stream_owner<%d, %d>" % (tile // 256, flavor), name
+        assert name == "csr_stream_owner<%d, %d, false>" % (tile // 256, flavor), name
     return T
 
 
@@ -755,7 +755,7 @@ def test_bench_script_tjds_format(torch):
                        capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
     j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
-    assert j["config"]["format"] == "tjds" and "TJDS" in j["metric"] and j["roofline"]["kernel"] == "csr_stream_owner<8, 3>"
+    assert j["config"]["format"] == "tjds" and "TJDS" in j["metric"] and j["roofline"]["kernel"] == "csr_stream_owner<8, 3, false>"
     assert j["extra"]["full_size_parity"]["y_equals_tiled_reference_memplus_y"] and j["value"] > 0
 
 

@@ -75,6 +75,57 @@ def test_two_rank_row_block_spmv(case, tmp_path):
     assert np.array_equal(y, ob.csr_spmv(row_ptr, col_ind, val, x))
 
 
+def _chunk_worker(rank, world, port, rows, chunks, overlap, out):
+    """ChunkedExchange (block-cyclic row chunks, one all-gather per chunk) exactly as bench.py's config-4 leg uses it."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ex = sharding.ChunkedExchange(torch, dist, rows, world, rank, chunks, "cpu")
+        x = np.random.default_rng(7).random(rows)
+        blocks = [sm.synth_csr(sm.SYNTH_UNIFORM, 2024, rows, rows, 5, r0, r1, threads=1) for r0, r1 in ex.ranges]
+        calls = []
+
+        def product(c, out_view):
+            r0, r1 = ex.ranges[c]
+            calls.append(c)
+            if r1 > r0:
+                out_view[:r1 - r0].copy_(torch.from_numpy(ob.csr_spmv(*blocks[c], x)))
+
+        for _ in range(2):                       # a second step must give the same vector (buffers are re-used)
+            y = ex.step(product, overlap=overlap)
+        assert calls == list(range(chunks)) * 2 and y.numel() == rows
+        ref = y.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(ref, y)               # every rank holds the same full vector
+        if rank == 0:
+            np.save(out, y.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,rows,chunks,overlap", [(2, 1000, 1, False), (2, 1003, 4, True), (4, 4099, 4, True),
+                                                        (4, 4099, 3, False), (4, 10, 4, True)])
+def test_chunked_exchange_block_cyclic(world, rows, chunks, overlap, tmp_path):
+    """world 2 and 4, chunk heights that do not divide the rows (short and empty last chunks), both step forms."""
+    out = str(tmp_path / "y.npy")
+    mp.spawn(_chunk_worker, args=(world, _free_port(), rows, chunks, overlap, out), nprocs=world, join=True)
+    rp, ci, v = sm.synth_csr(sm.SYNTH_UNIFORM, 2024, rows, rows, 5, threads=1)
+    assert np.array_equal(np.load(out), ob.csr_spmv(rp, ci, v, np.random.default_rng(7).random(rows)))
+
+
+def test_cyclic_chunk_rows_cover_every_row_once():
+    for rows, world, chunks in ((103, 4, 3), (16, 8, 4), (1, 2, 2), (10_000_000, 8, 4), (0, 2, 2)):
+        h, ranges = sharding.cyclic_chunk_rows(rows, world, chunks)
+        seen = np.zeros(rows, dtype=np.int32)
+        for r in range(world):
+            for c, (a, b) in enumerate(ranges[r]):
+                assert 0 <= a <= b <= rows and b - a <= h
+                assert a == min(rows, (c * world + r) * h)      # where the all-gather of chunk c puts rank r's rows
+                seen[a:b] += 1
+        assert np.all(seen == 1)
+    assert sharding.cyclic_chunk_rows(100, 4, 1)[1] == [[(0, 25)], [(25, 50)], [(50, 75)], [(75, 100)]]
+
+
 def test_bounds_helpers():
     b = sharding.equal_row_bounds(10, 4)
     assert b.tolist() == [0, 2, 5, 7, 10]
