@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/profile_bench.sh TAG  -- run on the GPU box (through gpurun): per-kernel times and HBM traffic of bench.py's
+# [PAT=substring] [BENCH_ARGS=..] tools/profile_bench.sh TAG  -- run on the GPU box (through gpurun): per-kernel times and HBM traffic of bench.py's
 # headline workload.  Writes gpurun_out/profile_TAG/{kernel_stats.csv, pmc_summary.txt, traffic.json, bench.json}.
 #   1. rocprofv3 --kernel-trace --stats on `bench.py --no-random-model --no-tjds --no-cpu-baseline`
 #   2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, TCC, SQ ...) on the same command, fewer steps
@@ -9,14 +9,15 @@ TAG=${1:-r01}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p "$OUT"
-ARGS="--no-random-model --no-tjds --no-cpu-baseline --no-samples ${BENCH_ARGS:-}"
+ARGS="--no-random-model --no-tjds --no-cpu-baseline --no-samples --no-config4 --no-pwt-tiled ${BENCH_ARGS:-}"
+PAT=${PAT:-csr_stream_owner<4, 0}   # kernel-name substring the PMC summary is taken over
 python3 $R/bench.py --steps 100 --warmup 10 $ARGS > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "bench failed"; tail -5 "$OUT/bench.err"; exit 1; }
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 $R/bench.py --steps 100 --warmup 10 $ARGS > "$OUT/trace.log" 2>&1 || echo "kernel-trace pass failed"
 cp "$OUT/trace/t_kernel_stats.csv" "$OUT/kernel_stats.csv" 2>/dev/null
 cd $R
 bash tools/pmc_passes.sh gpurun_out/profile_$TAG/pmc -- python3 $R/bench.py --steps 10 --warmup 2 $ARGS > /dev/null
-python3 tools/pmc_summary.py "$OUT/pmc" csr_stream_ > "$OUT/pmc_summary.txt"
+python3 tools/pmc_summary.py "$OUT/pmc" "$PAT" > "$OUT/pmc_summary.txt"
 python3 - "$OUT" <<'PY'
 import json, re, sys
 out = sys.argv[1]
