@@ -203,24 +203,40 @@ int smvp_tjds_describe(const smvp_tjds_t *h, char *kernel_name, size_t cap, doub
 void smvp_tjds_destroy(smvp_tjds_t *h);
 
 /* ------------------------------------------- several GPUs, one host process */
-/* New design (the reference is one CPU thread): the matrix is cut into `ngpus` row blocks of equal
- * height; GPU g holds block g as its own CSR / TJDS handle plus all of x and produces its slice of y;
- * one RCCL ncclAllGather over xGMI puts the full y on every GPU.  devices NULL = 0 .. ngpus-1.
- * librccl is dlopen'ed on first use.  (bench.py does the same with one process per GPU.) */
+/* New design (the reference is one CPU thread): the matrix is cut into `ngpus` row blocks balanced by entries
+ * (smvp_partition_rows); GPU g holds block g -- cut again into `chunks` row chunks, each its own CSR / TJDS handle --
+ * plus all of x and produces its slice of y; RCCL ncclAllGather over xGMI puts the full y on every GPU, chunk c
+ * travelling while chunk c+1 is multiplied.  devices NULL = 0 .. ngpus-1.  librccl is dlopen'ed on first use.
+ * (bench.py does the same with one process per GPU.)  Verified on hardware with ONE GPU only so far (no multi-GPU
+ * box is available to this project's tests); the N > 1 logic is covered by the gloo tests of the Python layer. */
 typedef struct smvp_sharded smvp_sharded_t;
+typedef struct smvp_shard_opts {
+    int chunks;  /* row chunks per GPU (the granularity of the product / all-gather overlap); 0 = 4 when ngpus > 1, else 1 */
+    int balance; /* 1 (default): blocks and chunks balanced by entries; 0: equal heights */
+} smvp_shard_opts_t;
+void smvp_shard_opts_default(smvp_shard_opts_t *o);
 int smvp_csr_sharded_create(smvp_sharded_t **out, int ngpus, const int *devices, int rows, int cols, int nnz,
                             const int *row_ptr, const int *col_ind, const double *val); /* host CSR arrays */
+int smvp_csr_sharded_create_ex(smvp_sharded_t **out, int ngpus, const int *devices, int rows, int cols, int nnz,
+                               const int *row_ptr, const int *col_ind, const double *val, const smvp_shard_opts_t *opts);
 int smvp_tjds_sharded_create(smvp_sharded_t **out, int ngpus, const int *devices, const smvp_coo_t *coo,
-                             int rows, int cols, int nnz); /* an independent TJDS per row block */
+                             int rows, int cols, int nnz); /* an independent TJDS per row chunk */
+int smvp_tjds_sharded_create_ex(smvp_sharded_t **out, int ngpus, const int *devices, const smvp_coo_t *coo,
+                                int rows, int cols, int nnz, const smvp_shard_opts_t *opts);
 int smvp_sharded_set_x(smvp_sharded_t *h, const double *x_host); /* NULL = ones; replicated to every GPU */
-/* local products on every GPU (+ the all-gather); asynchronous.  timed != 0 brackets it with an event pair per GPU */
+/* One product, asynchronous: the chunk products on every GPU and, by `allgather`, the exchange of y:
+ * 0 none; SMVP_GATHER_OVERLAPPED: chunk c is gathered (communication stream) while chunk c+1 is multiplied;
+ * SMVP_GATHER_AFTER: all gathers after all products.  timed != 0 brackets it with an event pair per GPU. */
+enum { SMVP_GATHER_NONE = 0, SMVP_GATHER_OVERLAPPED = 1, SMVP_GATHER_AFTER = 2 };
 int smvp_sharded_spmv(smvp_sharded_t *h, int allgather, int timed);
 int smvp_sharded_synchronize(smvp_sharded_t *h, double *ms_of_last_timed_product); /* max over the GPUs */
 /* power iteration: the gathered y (optionally divided by its largest magnitude) becomes x on every GPU;
  * call between two smvp_sharded_spmv(h, 1, ..), after which the all-gather is what feeds the next product */
 int smvp_sharded_feed_back(smvp_sharded_t *h, int normalize);
 int smvp_sharded_get_y(smvp_sharded_t *h, int slot, int gathered, double *y_host);
-int smvp_sharded_info(const smvp_sharded_t *h, int *ngpus, int *rows_per_gpu);
+int smvp_sharded_info(const smvp_sharded_t *h, int *ngpus, int *rows_per_gpu); /* rows_per_gpu = the tallest block */
+/* bounds[ngpus + 1] of the row blocks and chunk_bounds[ngpus * (chunks + 1)] of their chunks, global rows (NULL = skip) */
+int smvp_sharded_layout(const smvp_sharded_t *h, int *chunks, int *bounds, int *chunk_bounds);
 void smvp_sharded_destroy(smvp_sharded_t *h);
 
 /* ------------------------------------------------ reference-shaped entry points */

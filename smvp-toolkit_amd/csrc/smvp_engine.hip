@@ -1085,9 +1085,9 @@ int run_timed_products(RunScratch &s, int rows, int iters, const smvp_run_opts_t
             HIP_TRY(hipEventRecord(ev_start(s, i), s.stream));
             if (int rc = product(xc, yc, nullptr))
                 return rc;
-            if (o->iterate && o->normalize)
-                HIP_TRY(smvp::launch_normalize_max(yc, rows, s.d_norm, s.stream));
             HIP_TRY(hipEventRecord(ev_stop(s, i), s.stream));
+            if (o->iterate && o->normalize)  // scaling the iterate is not part of the product: outside the window,
+                HIP_TRY(smvp::launch_normalize_max(yc, rows, s.d_norm, s.stream));  // on one GPU and on several alike
             if (int rc = drain_ring(s, i, iters))
                 return rc;
             s.d_result = yc;
@@ -1134,7 +1134,7 @@ static int sharded_compute(bool tjds, const smvp_coo_t *coo, int rows, int cols,
     if (rc == SMVP_OK)
         rc = smvp_sharded_set_x(h, o->x);
     for (int i = 0; rc == SMVP_OK && i < iters; ++i) {
-        rc = smvp_sharded_spmv(h, 1, 1);
+        rc = smvp_sharded_spmv(h, SMVP_GATHER_OVERLAPPED, 1);
         if (rc == SMVP_OK)
             rc = smvp_sharded_synchronize(h, &time_each_ms[i]);
         if (rc == SMVP_OK && o->iterate && (i + 1 < iters || o->normalize))

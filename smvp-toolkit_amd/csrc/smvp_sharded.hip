@@ -1,14 +1,19 @@
 // smvp_sharded.hip -- one product over several GPUs of a node from ONE host process.
 //
 // The reference is a single thread on one CPU; this is new design:
-// the matrix is cut into row blocks of equal height, GPU g holds block g (its own
-// CSR or TJDS handle), all of x, and produces its slice of y; one RCCL
-// ncclAllGather over xGMI assembles the full y on every GPU.  bench.py does the
-// same with one process per GPU through torch.distributed; this file is what the
-// C command line (--gpus N) and smvp_*_compute(opts.ngpus > 1) use.
+// the matrix is cut into row blocks balanced by entries (smvp_partition_rows), GPU g
+// holds block g, all of x, and produces its slice of y; RCCL all-gathers over xGMI
+// assemble the full y on every GPU.  Each block is further cut into `chunks` row
+// chunks, each its own CSR / TJDS handle: the all-gather of chunk c (on the GPU's
+// communication stream) travels while chunk c+1 is being multiplied (on its compute
+// stream).  ncclAllGather wants equal counts, so a chunk goes onto the wire padded to
+// the tallest chunk c of any GPU and one small kernel per GPU then copies the
+// gathered pieces to their rows of the full vector.
+// bench.py does the same with one process per GPU through torch.distributed; this
+// file is what the C command line (--gpus N) and smvp_*_compute(opts.ngpus > 1) use.
 //
-// librccl is loaded with dlopen the first time more than zero GPUs are sharded,
-// so single-GPU runs neither link nor load it.
+// librccl is loaded with dlopen the first time a sharded handle is created, so
+// single-GPU runs neither link nor load it.
 #include "smvp_common.h"
 #include "smvp_kernels.h"
 
@@ -19,6 +24,8 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
+#include <string>
 #include <vector>
 
 #define HIP_TRY(expr)                                                                       \
@@ -38,48 +45,97 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    int status = SMVP_ERR_UNSUPPORTED;
+    std::string why;
 };
 
 int load_rccl(Rccl **out)
 {
     static Rccl r;
-    static int status = -1;
-    if (status < 0) {
+    static std::once_flag once;
+    std::call_once(once, [] {
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.lib)
                 break;
+            const char *err = dlerror();  // one call: it clears the message
+            r.why = err ? err : "dlopen failed";
         }
-        status = SMVP_ERR_UNSUPPORTED;
-        if (r.lib) {
-            r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.lib, "ncclCommInitAll");
-            r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
-            r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
-            r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
-            r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
-            r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
-            if (r.CommInitAll && r.CommDestroy && r.AllGather && r.GroupStart && r.GroupEnd && r.GetErrorString)
-                status = SMVP_OK;
-        }
-    }
-    if (status != SMVP_OK)
-        return smvp::fail(SMVP_ERR_UNSUPPORTED, "RCCL (librccl.so) could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+        if (!r.lib)
+            return;
+        const char *missing = nullptr;
+        auto sym = [&](const char *name) {
+            void *p = dlsym(r.lib, name);
+            if (!p && !missing)
+                missing = name;
+            return p;
+        };
+        r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        if (missing)
+            r.why = std::string("missing symbol ") + missing;
+        else
+            r.status = SMVP_OK;
+    });
+    if (r.status != SMVP_OK)
+        return smvp::fail(SMVP_ERR_UNSUPPORTED, "RCCL (librccl.so) could not be loaded: %s", r.why.c_str());
     *out = &r;
     return SMVP_OK;
+}
+
+// Runs what follows on `device` and puts the caller's device back afterwards.
+struct DeviceScope {
+    int prev = -1;
+    DeviceScope() { (void)hipGetDevice(&prev); }
+    ~DeviceScope()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
+// gathered pieces -> their rows of the full vector.  seg[i] = {first row in y_full, rows, offset in wire, 0}
+__global__ __launch_bounds__(256) void place_gathered(const double *__restrict__ wire, double *__restrict__ y_full,
+                                                      const int4 *__restrict__ seg, int nseg, int rows)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows)
+        return;
+    int lo = 0, hi = nseg - 1;  // last segment that starts at or before row r (empty segments share a start: take the last)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seg[mid].x <= r)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    y_full[r] = wire[(size_t)seg[lo].z + (size_t)(r - seg[lo].x)];
 }
 
 }  // namespace
 
 struct smvp_sharded {
     int format = 0;  // 0 = CSR, 1 = TJDS
-    int n = 0;
-    int rows = 0, cols = 0, nnz = 0, block = 0;  // block = rows per GPU (the last one may hold fewer)
-    std::vector<int> device, r0, r1;
-    std::vector<smvp_csr_t *> csr;
-    std::vector<smvp_tjds_t *> tjds;
-    std::vector<hipStream_t> stream;
-    std::vector<double *> d_x, d_y_local, d_y_full;
-    std::vector<hipEvent_t> ev0, ev1;
+    int n = 0, chunks = 1;
+    int rows = 0, cols = 0, nnz = 0;
+    std::vector<int> device;
+    std::vector<int> bounds;      // n + 1 block bounds (rows), balanced by entries
+    std::vector<int> cbounds;     // n * (chunks + 1): chunk bounds of every block, global rows
+    std::vector<int> pad;         // chunks: tallest chunk c over the GPUs = what travels per GPU for chunk c
+    std::vector<size_t> loff;     // chunks + 1: offset of chunk c in a GPU's y_local (padded slots)
+    std::vector<size_t> woff;     // chunks + 1: offset of chunk c's n * pad[c] block in the wire buffer
+    std::vector<smvp_csr_t *> csr;    // n * chunks
+    std::vector<smvp_tjds_t *> tjds;  // n * chunks
+    std::vector<hipStream_t> stream, comm_stream;
+    std::vector<double *> d_x, d_y_local, d_wire, d_y_full;
+    std::vector<int4 *> d_seg;
+    int nseg = 0;
+    std::vector<hipEvent_t> ev0, ev1, ev_gathered;
+    std::vector<hipEvent_t> ev_chunk;  // n * chunks
     std::vector<ncclComm_t> comm;
     std::vector<unsigned long long *> d_norm;
     Rccl *rccl = nullptr;
@@ -89,41 +145,67 @@ extern "C" void smvp_sharded_destroy(smvp_sharded_t *h)
 {
     if (!h)
         return;
+    DeviceScope keep;
     for (int g = 0; g < (int)h->device.size(); ++g) {
-        (void)hipSetDevice(h->device[(size_t)g]);
-        if (g < (int)h->comm.size() && h->comm[(size_t)g] && h->rccl)
-            h->rccl->CommDestroy(h->comm[(size_t)g]);
-        if (g < (int)h->csr.size())
-            smvp_csr_destroy(h->csr[(size_t)g]);
-        if (g < (int)h->tjds.size())
-            smvp_tjds_destroy(h->tjds[(size_t)g]);
-        for (auto *vec : {&h->d_x, &h->d_y_local, &h->d_y_full})
-            if (g < (int)vec->size() && (*vec)[(size_t)g])
-                (void)hipFree((*vec)[(size_t)g]);
-        if (g < (int)h->d_norm.size() && h->d_norm[(size_t)g])
-            (void)hipFree(h->d_norm[(size_t)g]);
-        if (g < (int)h->ev0.size() && h->ev0[(size_t)g])
-            (void)hipEventDestroy(h->ev0[(size_t)g]);
-        if (g < (int)h->ev1.size() && h->ev1[(size_t)g])
-            (void)hipEventDestroy(h->ev1[(size_t)g]);
-        if (g < (int)h->stream.size() && h->stream[(size_t)g])
-            (void)hipStreamDestroy(h->stream[(size_t)g]);
+        const size_t i = (size_t)g;
+        (void)hipSetDevice(h->device[i]);
+        if (i < h->comm.size() && h->comm[i] && h->rccl)
+            h->rccl->CommDestroy(h->comm[i]);
+        for (int c = 0; c < h->chunks; ++c) {
+            const size_t k = i * (size_t)h->chunks + (size_t)c;
+            if (k < h->csr.size())
+                smvp_csr_destroy(h->csr[k]);
+            if (k < h->tjds.size())
+                smvp_tjds_destroy(h->tjds[k]);
+            if (k < h->ev_chunk.size() && h->ev_chunk[k])
+                (void)hipEventDestroy(h->ev_chunk[k]);
+        }
+        for (auto *vec : {&h->d_x, &h->d_y_local, &h->d_wire, &h->d_y_full})
+            if (i < vec->size() && (*vec)[i])
+                (void)hipFree((*vec)[i]);
+        if (i < h->d_seg.size() && h->d_seg[i])
+            (void)hipFree(h->d_seg[i]);
+        if (i < h->d_norm.size() && h->d_norm[i])
+            (void)hipFree(h->d_norm[i]);
+        for (auto *vec : {&h->ev0, &h->ev1, &h->ev_gathered})
+            if (i < vec->size() && (*vec)[i])
+                (void)hipEventDestroy((*vec)[i]);
+        for (auto *vec : {&h->stream, &h->comm_stream})
+            if (i < vec->size() && (*vec)[i])
+                (void)hipStreamDestroy((*vec)[i]);
     }
     delete h;
 }
 
+extern "C" void smvp_shard_opts_default(smvp_shard_opts_t *o)
+{
+    if (!o)
+        return;
+    o->chunks = 0;
+    o->balance = 1;
+}
+
 namespace {
 
-int sharded_common(smvp_sharded *h, int ngpus, const int *devices, int rows, int cols, int nnz)
+// Block and chunk bounds, per-GPU buffers, streams, events, the communicator.  row_ptr: host CSR row pointer of the
+// whole matrix (what the partition is balanced on).
+int sharded_common(smvp_sharded *h, int ngpus, const int *devices, int rows, int cols, int nnz, const int *row_ptr,
+                   const smvp_shard_opts_t *opts)
 {
     int visible = 0;
     if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0)
         return smvp::fail(SMVP_ERR_NO_DEVICE, "no HIP device is visible (this engine has no CPU path)");
     if (ngpus < 1 || ngpus > visible)
         return smvp::fail(SMVP_ERR_INVALID, "%d GPUs requested, %d visible", ngpus, visible);
+    smvp_shard_opts_t def;
+    smvp_shard_opts_default(&def);
+    const smvp_shard_opts_t *o = opts ? opts : &def;
+    if (o->chunks < 0 || o->chunks > 64)
+        return smvp::fail(SMVP_ERR_INVALID, "chunks per GPU must lie in [1, 64] (0 = default)");
     h->n = ngpus;
+    h->chunks = o->chunks > 0 ? o->chunks : (ngpus > 1 ? 4 : 1);
     h->rows = rows, h->cols = cols, h->nnz = nnz;
-    h->block = std::max(1, (rows + ngpus - 1) / ngpus);
+    const size_t n = (size_t)ngpus, C = (size_t)h->chunks;
     for (int g = 0; g < ngpus; ++g) {
         const int dev = devices ? devices[g] : g;
         if (dev < 0 || dev >= visible)
@@ -132,31 +214,86 @@ int sharded_common(smvp_sharded *h, int ngpus, const int *devices, int rows, int
             if (p == dev)
                 return smvp::fail(SMVP_ERR_INVALID, "device %d listed twice", dev);
         h->device.push_back(dev);
-        h->r0.push_back(std::min(rows, g * h->block));
-        h->r1.push_back(std::min(rows, (g + 1) * h->block));
     }
-    h->stream.assign((size_t)ngpus, nullptr);
-    h->d_x.assign((size_t)ngpus, nullptr);
-    h->d_y_local.assign((size_t)ngpus, nullptr);
-    h->d_y_full.assign((size_t)ngpus, nullptr);
-    h->ev0.assign((size_t)ngpus, nullptr);
-    h->ev1.assign((size_t)ngpus, nullptr);
-    h->d_norm.assign((size_t)ngpus, nullptr);
-    for (int g = 0; g < ngpus; ++g) {
-        HIP_TRY(hipSetDevice(h->device[(size_t)g]));
-        HIP_TRY(hipStreamCreate(&h->stream[(size_t)g]));
-        HIP_TRY(hipEventCreate(&h->ev0[(size_t)g]));
-        HIP_TRY(hipEventCreate(&h->ev1[(size_t)g]));
-        HIP_TRY(hipMalloc((void **)&h->d_x[(size_t)g], sizeof(double) * (size_t)std::max(std::max(cols, rows), 1)));
-        HIP_TRY(hipMalloc((void **)&h->d_norm[(size_t)g], sizeof(unsigned long long)));
-        HIP_TRY(hipMalloc((void **)&h->d_y_local[(size_t)g], sizeof(double) * (size_t)h->block));
-        HIP_TRY(hipMalloc((void **)&h->d_y_full[(size_t)g], sizeof(double) * (size_t)h->block * (size_t)ngpus));
-        HIP_TRY(hipMemset(h->d_y_local[(size_t)g], 0, sizeof(double) * (size_t)h->block));
-        HIP_TRY(hipMemset(h->d_y_full[(size_t)g], 0, sizeof(double) * (size_t)h->block * (size_t)ngpus));
+    // blocks balanced by entries (or of equal height), every block cut into chunks the same way
+    h->bounds.assign(n + 1, 0);
+    if (o->balance) {
+        if (int rc = smvp_partition_rows(row_ptr, rows, ngpus, h->bounds.data()))
+            return rc;
+    } else {
+        for (int g = 0; g <= ngpus; ++g)
+            h->bounds[(size_t)g] = (int)((long long)rows * g / ngpus);
+    }
+    h->cbounds.assign(n * (C + 1), 0);
+    h->pad.assign(C, 0);
+    for (size_t g = 0; g < n; ++g) {
+        const int a = h->bounds[g], b = h->bounds[g + 1];
+        std::vector<int> local((size_t)(b - a) + 1), cb(C + 1);
+        for (int r = a; r <= b; ++r)
+            local[(size_t)(r - a)] = row_ptr[r] - row_ptr[a];
+        if (o->balance) {
+            if (int rc = smvp_partition_rows(local.data(), b - a, h->chunks, cb.data()))
+                return rc;
+        } else {
+            for (size_t c = 0; c <= C; ++c)
+                cb[c] = (int)((long long)(b - a) * (long long)c / (long long)C);
+        }
+        for (size_t c = 0; c <= C; ++c)
+            h->cbounds[g * (C + 1) + c] = a + cb[c];
+        for (size_t c = 0; c < C; ++c)
+            h->pad[c] = std::max(h->pad[c], cb[c + 1] - cb[c]);
+    }
+    h->loff.assign(C + 1, 0);
+    h->woff.assign(C + 1, 0);
+    for (size_t c = 0; c < C; ++c) {
+        h->pad[c] = std::max(h->pad[c], 1);
+        h->loff[c + 1] = h->loff[c] + (size_t)h->pad[c];
+        h->woff[c + 1] = h->woff[c] + (size_t)h->pad[c] * n;
+    }
+    // where every gathered piece belongs: segments in ascending row order (block-major, chunk-minor)
+    std::vector<int4> seg;
+    for (size_t g = 0; g < n; ++g)
+        for (size_t c = 0; c < C; ++c) {
+            const int a = h->cbounds[g * (C + 1) + c], b = h->cbounds[g * (C + 1) + c + 1];
+            seg.push_back(make_int4(a, b - a, (int)(h->woff[c] + g * (size_t)h->pad[c]), 0));
+        }
+    if (h->woff[C] > 2147483647ull)
+        return smvp::fail(SMVP_ERR_UNSUPPORTED, "the padded wire buffer exceeds 2^31 entries");
+    h->nseg = (int)seg.size();
+
+    h->stream.assign(n, nullptr);
+    h->comm_stream.assign(n, nullptr);
+    for (auto *vec : {&h->d_x, &h->d_y_local, &h->d_wire, &h->d_y_full})
+        vec->assign(n, nullptr);
+    h->d_seg.assign(n, nullptr);
+    for (auto *vec : {&h->ev0, &h->ev1, &h->ev_gathered})
+        vec->assign(n, nullptr);
+    h->ev_chunk.assign(n * C, nullptr);
+    h->d_norm.assign(n, nullptr);
+    const size_t vec_len = (size_t)std::max(std::max(cols, rows), 1);
+    for (size_t g = 0; g < n; ++g) {
+        HIP_TRY(hipSetDevice(h->device[g]));
+        HIP_TRY(hipStreamCreate(&h->stream[g]));
+        HIP_TRY(hipStreamCreate(&h->comm_stream[g]));
+        for (auto *vec : {&h->ev0, &h->ev1})
+            HIP_TRY(hipEventCreate(&(*vec)[g]));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_gathered[g], hipEventDisableTiming));
+        for (size_t c = 0; c < C; ++c)
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_chunk[g * C + c], hipEventDisableTiming));
+        HIP_TRY(hipMalloc((void **)&h->d_x[g], sizeof(double) * vec_len));
+        HIP_TRY(hipMalloc((void **)&h->d_norm[g], sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void **)&h->d_y_local[g], sizeof(double) * h->loff[C]));
+        HIP_TRY(hipMalloc((void **)&h->d_wire[g], sizeof(double) * h->woff[C]));
+        HIP_TRY(hipMalloc((void **)&h->d_y_full[g], sizeof(double) * vec_len));
+        HIP_TRY(hipMalloc((void **)&h->d_seg[g], sizeof(int4) * seg.size()));
+        HIP_TRY(hipMemset(h->d_y_local[g], 0, sizeof(double) * h->loff[C]));
+        HIP_TRY(hipMemset(h->d_wire[g], 0, sizeof(double) * h->woff[C]));
+        HIP_TRY(hipMemset(h->d_y_full[g], 0, sizeof(double) * vec_len));
+        HIP_TRY(hipMemcpy(h->d_seg[g], seg.data(), sizeof(int4) * seg.size(), hipMemcpyHostToDevice));
     }
     if (int rc = load_rccl(&h->rccl))
         return rc;
-    h->comm.assign((size_t)ngpus, nullptr);
+    h->comm.assign(n, nullptr);
     ncclResult_t nr = h->rccl->CommInitAll(h->comm.data(), ngpus, h->device.data());
     if (nr != ncclSuccess)
         return smvp::fail(SMVP_ERR_HIP, "ncclCommInitAll failed: %s", h->rccl->GetErrorString(nr));
@@ -165,22 +302,98 @@ int sharded_common(smvp_sharded *h, int ngpus, const int *devices, int rows, int
 
 }  // namespace
 
-extern "C" int smvp_csr_sharded_create(smvp_sharded_t **out, int ngpus, const int *devices, int rows, int cols, int nnz,
-                                       const int *row_ptr, const int *col_ind, const double *val)
+extern "C" int smvp_csr_sharded_create_ex(smvp_sharded_t **out, int ngpus, const int *devices, int rows, int cols, int nnz,
+                                          const int *row_ptr, const int *col_ind, const double *val,
+                                          const smvp_shard_opts_t *opts)
 {
     if (!out || rows < 0 || cols < 0 || nnz < 0 || !row_ptr || (nnz > 0 && (!col_ind || !val)))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_sharded_create: bad argument");
+    if (row_ptr[0] != 0 || row_ptr[rows] != nnz)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_sharded_create: row_ptr does not run from 0 to nnz");
+    DeviceScope keep;
     smvp_sharded *h = new smvp_sharded;
     h->format = 0;
-    int rc = sharded_common(h, ngpus, devices, rows, cols, nnz);
-    h->csr.assign((size_t)std::max(ngpus, 0), nullptr);
-    for (int g = 0; rc == SMVP_OK && g < ngpus; ++g) {
-        const int a = h->r0[(size_t)g], b = h->r1[(size_t)g];
-        std::vector<int> rp((size_t)(b - a) + 1);
-        for (int r = a; r <= b; ++r)
-            rp[(size_t)(r - a)] = row_ptr[r] - row_ptr[a];
-        rc = smvp_csr_create(&h->csr[(size_t)g], h->device[(size_t)g], b - a, cols, row_ptr[b] - row_ptr[a], rp.data(),
-                             col_ind + row_ptr[a], val + row_ptr[a], SMVP_MEM_HOST, nullptr);
+    int rc = sharded_common(h, ngpus, devices, rows, cols, nnz, row_ptr, opts);
+    const size_t C = (size_t)h->chunks;
+    h->csr.assign((size_t)std::max(ngpus, 0) * C, nullptr);
+    for (size_t g = 0; rc == SMVP_OK && g < (size_t)ngpus; ++g)
+        for (size_t c = 0; rc == SMVP_OK && c < C; ++c) {
+            const int a = h->cbounds[g * (C + 1) + c], b = h->cbounds[g * (C + 1) + c + 1];
+            std::vector<int> rp((size_t)(b - a) + 1);
+            for (int r = a; r <= b; ++r)
+                rp[(size_t)(r - a)] = row_ptr[r] - row_ptr[a];
+            rc = smvp_csr_create(&h->csr[g * C + c], h->device[g], b - a, cols, row_ptr[b] - row_ptr[a], rp.data(),
+                                 col_ind + row_ptr[a], val + row_ptr[a], SMVP_MEM_HOST, nullptr);
+        }
+    if (rc != SMVP_OK) {
+        smvp_sharded_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return SMVP_OK;
+}
+
+extern "C" int smvp_csr_sharded_create(smvp_sharded_t **out, int ngpus, const int *devices, int rows, int cols, int nnz,
+                                       const int *row_ptr, const int *col_ind, const double *val)
+{
+    return smvp_csr_sharded_create_ex(out, ngpus, devices, rows, cols, nnz, row_ptr, col_ind, val, nullptr);
+}
+
+extern "C" int smvp_tjds_sharded_create_ex(smvp_sharded_t **out, int ngpus, const int *devices, const smvp_coo_t *coo,
+                                           int rows, int cols, int nnz, const smvp_shard_opts_t *opts)
+{
+    if (!out || rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && !coo))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_sharded_create: bad argument");
+    // entries per row -> the row pointer the partition is balanced on; then every entry goes to its chunk once
+    std::vector<int> row_ptr((size_t)rows + 1, 0);
+    for (int i = 0; i < nnz; ++i) {
+        if (coo[i].row < 0 || coo[i].row >= rows)
+            return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_sharded_create: entry %d lies outside the matrix", i);
+        ++row_ptr[(size_t)coo[i].row + 1];
+    }
+    for (int r = 0; r < rows; ++r)
+        row_ptr[(size_t)r + 1] += row_ptr[(size_t)r];
+    DeviceScope keep;
+    smvp_sharded *h = new smvp_sharded;
+    h->format = 1;
+    int rc = sharded_common(h, ngpus, devices, rows, cols, nnz, row_ptr.data(), opts);
+    const size_t C = (size_t)h->chunks, parts = (size_t)std::max(ngpus, 0) * C;
+    h->tjds.assign(parts, nullptr);
+    if (rc == SMVP_OK) {
+        // chunk of every row, then one counting pass buckets the entries (input order kept inside a chunk)
+        std::vector<int> chunk_of((size_t)rows), first((size_t)rows);
+        std::vector<size_t> start(parts + 1, 0);
+        for (size_t g = 0; g < (size_t)ngpus; ++g)
+            for (size_t c = 0; c < C; ++c) {
+                const int a = h->cbounds[g * (C + 1) + c], b = h->cbounds[g * (C + 1) + c + 1];
+                for (int r = a; r < b; ++r) {
+                    chunk_of[(size_t)r] = (int)(g * C + c);
+                    first[(size_t)r] = a;
+                }
+                start[g * C + c + 1] = start[g * C + c] + (size_t)(row_ptr[(size_t)b] - row_ptr[(size_t)a]);
+            }
+        std::vector<smvp_coo_t> bucket((size_t)std::max(nnz, 1));
+        std::vector<size_t> fill(start.begin(), start.end() - 1);
+        for (int i = 0; i < nnz; ++i) {
+            smvp_coo_t e = coo[i];
+            const size_t k = (size_t)chunk_of[(size_t)e.row];
+            e.row -= first[(size_t)coo[i].row];
+            bucket[fill[k]++] = e;
+        }
+        // an independent TJDS per row chunk: its output is a disjoint slice of y, so the same all-gather applies
+        for (size_t k = 0; rc == SMVP_OK && k < parts; ++k) {
+            const size_t g = k / C, c = k % C;
+            const int a = h->cbounds[g * (C + 1) + c], b = h->cbounds[g * (C + 1) + c + 1];
+            const int pn = (int)(start[k + 1] - start[k]);
+            std::vector<int> perm((size_t)std::max(cols, 1)), sp((size_t)std::max(b - a, pn) + 2), ri((size_t)std::max(pn, 1));
+            std::vector<double> v((size_t)std::max(pn, 1));
+            int nd = 0;
+            rc = smvp_tjds_from_coo(bucket.data() + start[k], b - a, cols, pn, perm.data(), sp.data(), (int)sp.size(), ri.data(),
+                                    v.data(), &nd, nullptr, nullptr);
+            if (rc == SMVP_OK)
+                rc = smvp_tjds_create(&h->tjds[k], h->device[g], b - a, cols, pn, nd, perm.data(), sp.data(), ri.data(),
+                                      v.data(), SMVP_MEM_HOST);
+        }
     }
     if (rc != SMVP_OK) {
         smvp_sharded_destroy(h);
@@ -193,38 +406,22 @@ extern "C" int smvp_csr_sharded_create(smvp_sharded_t **out, int ngpus, const in
 extern "C" int smvp_tjds_sharded_create(smvp_sharded_t **out, int ngpus, const int *devices, const smvp_coo_t *coo,
                                         int rows, int cols, int nnz)
 {
-    if (!out || rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && !coo))
-        return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_sharded_create: bad argument");
-    smvp_sharded *h = new smvp_sharded;
-    h->format = 1;
-    int rc = sharded_common(h, ngpus, devices, rows, cols, nnz);
-    h->tjds.assign((size_t)std::max(ngpus, 0), nullptr);
-    // an independent TJDS per row block: its output is a disjoint slice of y, so the same all-gather applies
-    for (int g = 0; rc == SMVP_OK && g < ngpus; ++g) {
-        const int a = h->r0[(size_t)g], b = h->r1[(size_t)g];
-        std::vector<smvp_coo_t> part;
-        for (int i = 0; i < nnz; ++i)
-            if (coo[i].row >= a && coo[i].row < b) {
-                part.push_back(coo[i]);
-                part.back().row -= a;
-            }
-        const int pn = (int)part.size();
-        std::vector<int> perm((size_t)std::max(cols, 1)), sp((size_t)std::max(b - a, pn) + 2), ri((size_t)std::max(pn, 1));
-        std::vector<double> v((size_t)std::max(pn, 1));
-        int nd = 0;
-        rc = smvp_tjds_from_coo(part.data(), b - a, cols, pn, perm.data(), sp.data(), (int)sp.size(), ri.data(), v.data(),
-                                &nd, nullptr, nullptr);
-        if (rc == SMVP_OK)
-            rc = smvp_tjds_create(&h->tjds[(size_t)g], h->device[(size_t)g], b - a, cols, pn, nd, perm.data(), sp.data(),
-                                  ri.data(), v.data(), SMVP_MEM_HOST);
-    }
-    if (rc != SMVP_OK) {
-        smvp_sharded_destroy(h);
-        return rc;
-    }
-    *out = h;
+    return smvp_tjds_sharded_create_ex(out, ngpus, devices, coo, rows, cols, nnz, nullptr);
+}
+
+namespace {
+
+int set_operand_everywhere(smvp_sharded *h, size_t g)
+{
+    if (h->format != 1)
+        return SMVP_OK;
+    for (size_t c = 0; c < (size_t)h->chunks; ++c)
+        if (int rc = smvp_tjds_set_x(h->tjds[g * (size_t)h->chunks + c], h->d_x[g], h->stream[g]))
+            return rc;
     return SMVP_OK;
 }
+
+}  // namespace
 
 extern "C" int smvp_sharded_set_x(smvp_sharded_t *h, const double *x_host)
 {
@@ -235,51 +432,78 @@ extern "C" int smvp_sharded_set_x(smvp_sharded_t *h, const double *x_host)
         ones.assign((size_t)std::max(h->cols, 1), 1.0);
         x_host = ones.data();
     }
-    for (int g = 0; g < h->n; ++g) {
-        HIP_TRY(hipSetDevice(h->device[(size_t)g]));
-        HIP_TRY(hipMemcpy(h->d_x[(size_t)g], x_host, sizeof(double) * (size_t)h->cols, hipMemcpyHostToDevice));
-        if (h->format == 1)
-            if (int rc = smvp_tjds_set_x(h->tjds[(size_t)g], h->d_x[(size_t)g], h->stream[(size_t)g]))
-                return rc;
+    DeviceScope keep;
+    for (size_t g = 0; g < (size_t)h->n; ++g) {
+        HIP_TRY(hipSetDevice(h->device[g]));
+        HIP_TRY(hipMemcpy(h->d_x[g], x_host, sizeof(double) * (size_t)h->cols, hipMemcpyHostToDevice));
+        if (int rc = set_operand_everywhere(h, g))
+            return rc;
     }
     return SMVP_OK;
 }
 
-// One product: local products on every GPU, then (allgather != 0) one grouped ncclAllGather.  `timed` records the
-// event pair on every GPU around exactly that; TJDS blocks clear their y slice first, outside the pair.
+// One product: on every GPU the chunk products in turn on its compute stream; allgather = SMVP_GATHER_OVERLAPPED: the
+// ncclAllGather of chunk c is issued on the communication streams as soon as every GPU has produced its chunk c,
+// while the later chunks are still being multiplied; SMVP_GATHER_AFTER: all gathers on the compute streams after all
+// products (nothing overlapped); 0: local products only.  Then one kernel per GPU copies the gathered pieces to
+// their rows of the full vector.  `timed` brackets all of it with an event pair per GPU; TJDS chunks that need a
+// cleared y get it first, outside the pair (main-cli.c:1008).
 extern "C" int smvp_sharded_spmv(smvp_sharded_t *h, int allgather, int timed)
 {
-    if (!h)
-        return smvp::fail(SMVP_ERR_INVALID, "null handle");
-    for (int g = 0; g < h->n; ++g) {
-        const size_t i = (size_t)g;
-        HIP_TRY(hipSetDevice(h->device[i]));
+    if (!h || allgather < 0 || allgather > SMVP_GATHER_AFTER)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_sharded_spmv: bad argument");
+    DeviceScope keep;
+    const size_t n = (size_t)h->n, C = (size_t)h->chunks;
+    const bool overlap = allgather == SMVP_GATHER_OVERLAPPED;
+    for (size_t g = 0; g < n; ++g) {
+        HIP_TRY(hipSetDevice(h->device[g]));
         if (h->format == 1)
-            if (int rc = smvp_tjds_zero_y(h->tjds[i], h->d_y_local[i], h->stream[i]))
-                return rc;
+            for (size_t c = 0; c < C; ++c)
+                if (int rc = smvp_tjds_zero_y(h->tjds[g * C + c], h->d_y_local[g] + h->loff[c], h->stream[g]))
+                    return rc;
         if (timed)
-            HIP_TRY(hipEventRecord(h->ev0[i], h->stream[i]));
-        const int rc = h->format == 0 ? smvp_csr_spmv(h->csr[i], h->d_x[i], h->d_y_local[i], h->stream[i])
-                                      : smvp_tjds_spmv(h->tjds[i], h->d_y_local[i], h->stream[i]);
-        if (rc != SMVP_OK)
-            return rc;
+            HIP_TRY(hipEventRecord(h->ev0[g], h->stream[g]));
+        for (size_t c = 0; c < C; ++c) {
+            double *yc = h->d_y_local[g] + h->loff[c];
+            const int rc = h->format == 0 ? smvp_csr_spmv(h->csr[g * C + c], h->d_x[g], yc, h->stream[g])
+                                          : smvp_tjds_spmv(h->tjds[g * C + c], yc, h->stream[g]);
+            if (rc != SMVP_OK)
+                return rc;
+            if (overlap) {
+                HIP_TRY(hipEventRecord(h->ev_chunk[g * C + c], h->stream[g]));
+                HIP_TRY(hipStreamWaitEvent(h->comm_stream[g], h->ev_chunk[g * C + c], 0));
+            }
+        }
     }
     if (allgather) {
-        ncclResult_t nr = h->rccl->GroupStart();
-        for (int g = 0; g < h->n && nr == ncclSuccess; ++g) {
-            const size_t i = (size_t)g;
-            nr = h->rccl->AllGather(h->d_y_local[i], h->d_y_full[i], (size_t)h->block, ncclDouble, h->comm[i], h->stream[i]);
+        for (size_t c = 0; c < C; ++c) {
+            ncclResult_t nr = h->rccl->GroupStart();
+            for (size_t g = 0; g < n && nr == ncclSuccess; ++g)
+                nr = h->rccl->AllGather(h->d_y_local[g] + h->loff[c], h->d_wire[g] + h->woff[c], (size_t)h->pad[c], ncclDouble,
+                                        h->comm[g], overlap ? h->comm_stream[g] : h->stream[g]);
+            const ncclResult_t ne = h->rccl->GroupEnd();
+            if (nr == ncclSuccess)
+                nr = ne;
+            if (nr != ncclSuccess)
+                return smvp::fail(SMVP_ERR_HIP, "ncclAllGather failed: %s", h->rccl->GetErrorString(nr));
         }
-        const ncclResult_t ne = h->rccl->GroupEnd();
-        if (nr == ncclSuccess)
-            nr = ne;
-        if (nr != ncclSuccess)
-            return smvp::fail(SMVP_ERR_HIP, "ncclAllGather failed: %s", h->rccl->GetErrorString(nr));
+        for (size_t g = 0; g < n; ++g) {
+            HIP_TRY(hipSetDevice(h->device[g]));
+            if (overlap) {
+                HIP_TRY(hipEventRecord(h->ev_gathered[g], h->comm_stream[g]));
+                HIP_TRY(hipStreamWaitEvent(h->stream[g], h->ev_gathered[g], 0));
+            }
+            if (h->rows > 0) {
+                hipLaunchKernelGGL(place_gathered, dim3((unsigned)((h->rows + 255) / 256)), dim3(256), 0, h->stream[g],
+                                   h->d_wire[g], h->d_y_full[g], h->d_seg[g], h->nseg, h->rows);
+                HIP_TRY(hipGetLastError());
+            }
+        }
     }
     if (timed)
-        for (int g = 0; g < h->n; ++g) {
-            HIP_TRY(hipSetDevice(h->device[(size_t)g]));
-            HIP_TRY(hipEventRecord(h->ev1[(size_t)g], h->stream[(size_t)g]));
+        for (size_t g = 0; g < n; ++g) {
+            HIP_TRY(hipSetDevice(h->device[g]));
+            HIP_TRY(hipEventRecord(h->ev1[g], h->stream[g]));
         }
     return SMVP_OK;
 }
@@ -292,16 +516,15 @@ extern "C" int smvp_sharded_feed_back(smvp_sharded_t *h, int normalize)
         return smvp::fail(SMVP_ERR_INVALID, "null handle");
     if (h->rows != h->cols)
         return smvp::fail(SMVP_ERR_INVALID, "power iteration needs a square matrix");
-    for (int g = 0; g < h->n; ++g) {
-        const size_t i = (size_t)g;
-        HIP_TRY(hipSetDevice(h->device[i]));
+    DeviceScope keep;
+    for (size_t g = 0; g < (size_t)h->n; ++g) {
+        HIP_TRY(hipSetDevice(h->device[g]));
         if (normalize)
-            HIP_TRY(smvp::launch_normalize_max(h->d_y_full[i], h->rows, h->d_norm[i], h->stream[i]));
-        HIP_TRY(hipMemcpyAsync(h->d_x[i], h->d_y_full[i], sizeof(double) * (size_t)h->rows, hipMemcpyDeviceToDevice,
-                               h->stream[i]));
-        if (h->format == 1)
-            if (int rc = smvp_tjds_set_x(h->tjds[i], h->d_x[i], h->stream[i]))
-                return rc;
+            HIP_TRY(smvp::launch_normalize_max(h->d_y_full[g], h->rows, h->d_norm[g], h->stream[g]));
+        HIP_TRY(hipMemcpyAsync(h->d_x[g], h->d_y_full[g], sizeof(double) * (size_t)h->rows, hipMemcpyDeviceToDevice,
+                               h->stream[g]));
+        if (int rc = set_operand_everywhere(h, g))
+            return rc;
     }
     return SMVP_OK;
 }
@@ -311,13 +534,15 @@ extern "C" int smvp_sharded_synchronize(smvp_sharded_t *h, double *ms)
 {
     if (!h)
         return smvp::fail(SMVP_ERR_INVALID, "null handle");
+    DeviceScope keep;
     double worst = 0.0;
-    for (int g = 0; g < h->n; ++g) {
-        HIP_TRY(hipSetDevice(h->device[(size_t)g]));
-        HIP_TRY(hipStreamSynchronize(h->stream[(size_t)g]));
+    for (size_t g = 0; g < (size_t)h->n; ++g) {
+        HIP_TRY(hipSetDevice(h->device[g]));
+        HIP_TRY(hipStreamSynchronize(h->comm_stream[g]));
+        HIP_TRY(hipStreamSynchronize(h->stream[g]));
         if (ms) {
             float t = 0.f;
-            if (hipEventElapsedTime(&t, h->ev0[(size_t)g], h->ev1[(size_t)g]) == hipSuccess)
+            if (hipEventElapsedTime(&t, h->ev0[g], h->ev1[g]) == hipSuccess)
                 worst = std::max(worst, (double)t);
         }
     }
@@ -331,17 +556,21 @@ extern "C" int smvp_sharded_get_y(smvp_sharded_t *h, int slot, int gathered, dou
 {
     if (!h || slot < 0 || slot >= h->n || (h->rows > 0 && !y_host))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_sharded_get_y: bad argument");
+    DeviceScope keep;
     if (gathered) {
         HIP_TRY(hipSetDevice(h->device[(size_t)slot]));
         if (h->rows > 0)
             HIP_TRY(hipMemcpy(y_host, h->d_y_full[(size_t)slot], sizeof(double) * (size_t)h->rows, hipMemcpyDeviceToHost));
         return SMVP_OK;
     }
-    for (int g = 0; g < h->n; ++g) {
-        const int a = h->r0[(size_t)g], b = h->r1[(size_t)g];
-        HIP_TRY(hipSetDevice(h->device[(size_t)g]));
-        if (b > a)
-            HIP_TRY(hipMemcpy(y_host + a, h->d_y_local[(size_t)g], sizeof(double) * (size_t)(b - a), hipMemcpyDeviceToHost));
+    const size_t C = (size_t)h->chunks;
+    for (size_t g = 0; g < (size_t)h->n; ++g) {
+        HIP_TRY(hipSetDevice(h->device[g]));
+        for (size_t c = 0; c < C; ++c) {
+            const int a = h->cbounds[g * (C + 1) + c], b = h->cbounds[g * (C + 1) + c + 1];
+            if (b > a)
+                HIP_TRY(hipMemcpy(y_host + a, h->d_y_local[g] + h->loff[c], sizeof(double) * (size_t)(b - a), hipMemcpyDeviceToHost));
+        }
     }
     return SMVP_OK;
 }
@@ -352,7 +581,25 @@ extern "C" int smvp_sharded_info(const smvp_sharded_t *h, int *ngpus, int *rows_
         return smvp::fail(SMVP_ERR_INVALID, "null handle");
     if (ngpus)
         *ngpus = h->n;
-    if (rows_per_gpu)
-        *rows_per_gpu = h->block;
+    if (rows_per_gpu) {  // the tallest block
+        int tallest = 0;
+        for (int g = 0; g < h->n; ++g)
+            tallest = std::max(tallest, h->bounds[(size_t)g + 1] - h->bounds[(size_t)g]);
+        *rows_per_gpu = tallest;
+    }
+    return SMVP_OK;
+}
+
+// bounds[ngpus + 1] of the row blocks and, if asked for, chunk_bounds[ngpus * (chunks + 1)] of their chunks (global rows)
+extern "C" int smvp_sharded_layout(const smvp_sharded_t *h, int *chunks, int *bounds, int *chunk_bounds)
+{
+    if (!h)
+        return smvp::fail(SMVP_ERR_INVALID, "null handle");
+    if (chunks)
+        *chunks = h->chunks;
+    if (bounds)
+        memcpy(bounds, h->bounds.data(), sizeof(int) * h->bounds.size());
+    if (chunk_bounds)
+        memcpy(chunk_bounds, h->cbounds.data(), sizeof(int) * h->cbounds.size());
     return SMVP_OK;
 }

@@ -43,6 +43,13 @@ class RunInfo(C.Structure):
     _fields_ = [("timing", C.c_int), ("graph_replays", C.c_int), ("wall_ms", C.c_double), ("device_clock_khz", C.c_double)]
 
 
+class ShardOpts(C.Structure):
+    _fields_ = [("chunks", C.c_int), ("balance", C.c_int)]
+
+
+GATHER_NONE, GATHER_OVERLAPPED, GATHER_AFTER = 0, 1, 2
+
+
 class SmvpError(RuntimeError):
     def __init__(self, code, where):
         self.code = code
@@ -63,7 +70,8 @@ EXPORTS = [
     "smvp_csr_describe", "smvp_csr_destroy",
     "smvp_tjds_create", "smvp_tjds_set_x", "smvp_tjds_zero_y", "smvp_tjds_spmv",
     "smvp_tjds_set_ref_quirks", "smvp_tjds_set_mode", "smvp_tjds_set_tile", "smvp_tjds_describe", "smvp_tjds_destroy",
-    "smvp_csr_sharded_create", "smvp_tjds_sharded_create", "smvp_sharded_set_x", "smvp_sharded_spmv",
+    "smvp_shard_opts_default", "smvp_csr_sharded_create", "smvp_csr_sharded_create_ex", "smvp_tjds_sharded_create",
+    "smvp_tjds_sharded_create_ex", "smvp_sharded_layout", "smvp_sharded_set_x", "smvp_sharded_spmv",
     "smvp_sharded_synchronize", "smvp_sharded_feed_back", "smvp_sharded_get_y", "smvp_sharded_info", "smvp_sharded_destroy",
     "smvp_run_opts_default", "smvp_csr_compute", "smvp_tjds_compute", "smvp_last_run_info",
     "smvp_time_stats", "smvp_generate_report_text",
@@ -104,6 +112,11 @@ def lib():
         L.smvp_tjds_from_coo.argtypes = [vp, ci, ci, ci, vp, vp, ci, vp, vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
         L.smvp_csr_sharded_create.argtypes = [C.POINTER(vp), ci, vp, ci, ci, ci, vp, vp, vp]
         L.smvp_tjds_sharded_create.argtypes = [C.POINTER(vp), ci, vp, vp, ci, ci, ci]
+        L.smvp_csr_sharded_create_ex.argtypes = [C.POINTER(vp), ci, vp, ci, ci, ci, vp, vp, vp, C.POINTER(ShardOpts)]
+        L.smvp_tjds_sharded_create_ex.argtypes = [C.POINTER(vp), ci, vp, vp, ci, ci, ci, C.POINTER(ShardOpts)]
+        L.smvp_shard_opts_default.argtypes = [C.POINTER(ShardOpts)]
+        L.smvp_shard_opts_default.restype = None
+        L.smvp_sharded_layout.argtypes = [vp, C.POINTER(ci), vp, vp]
         L.smvp_sharded_set_x.argtypes = [vp, vp]
         L.smvp_sharded_spmv.argtypes = [vp, ci, ci]
         L.smvp_sharded_synchronize.argtypes = [vp, C.POINTER(C.c_double)]
@@ -412,26 +425,40 @@ class TjdsMatrix:
 class ShardedMatrix:
     """Row blocks of one matrix on several GPUs of this process (smvp_sharded_t), RCCL all-gather of y."""
 
-    def __init__(self, fmt, ngpus, rows, cols, coo=None, csr=None, devices=None):
+    def __init__(self, fmt, ngpus, rows, cols, coo=None, csr=None, devices=None, chunks=0, balance=True):
         self._h = C.c_void_p()
         devs = None if devices is None else (C.c_int * ngpus)(*devices)
+        o = ShardOpts()
+        lib().smvp_shard_opts_default(C.byref(o))
+        o.chunks, o.balance = int(chunks), int(balance)
         if fmt == "csr":
             rp, ci, v = csr
             nnz = int(rp[rows])
-            _check(lib().smvp_csr_sharded_create(C.byref(self._h), ngpus, devs, rows, cols, nnz, _p(_arr(rp, np.int32)),
-                                                 _p(_arr(ci, np.int32)), _p(_arr(v, np.float64))),
-                   "smvp_csr_sharded_create")
+            _check(lib().smvp_csr_sharded_create_ex(C.byref(self._h), ngpus, devs, rows, cols, nnz, _p(_arr(rp, np.int32)),
+                                                    _p(_arr(ci, np.int32)), _p(_arr(v, np.float64)), C.byref(o)),
+                   "smvp_csr_sharded_create_ex")
         else:
             nnz = len(coo)
-            _check(lib().smvp_tjds_sharded_create(C.byref(self._h), ngpus, devs, _p(_arr(coo, COO_DTYPE)), rows, cols,
-                                                  nnz), "smvp_tjds_sharded_create")
+            _check(lib().smvp_tjds_sharded_create_ex(C.byref(self._h), ngpus, devs, _p(_arr(coo, COO_DTYPE)), rows, cols,
+                                                     nnz, C.byref(o)), "smvp_tjds_sharded_create_ex")
         self.rows, self.cols = rows, cols
+
+    def layout(self):
+        """(chunks per GPU, block bounds[ngpus + 1], chunk bounds[ngpus][chunks + 1]) in global rows."""
+        n, _ = self.info()
+        c = C.c_int()
+        _check(lib().smvp_sharded_layout(self._h, C.byref(c), None, None), "smvp_sharded_layout")
+        bounds = np.zeros(n + 1, dtype=np.int32)
+        cb = np.zeros(n * (c.value + 1), dtype=np.int32)
+        _check(lib().smvp_sharded_layout(self._h, C.byref(c), _p(bounds), _p(cb)), "smvp_sharded_layout")
+        return c.value, bounds, cb.reshape(n, c.value + 1)
 
     def set_x(self, x=None):
         keep = None if x is None else _arr(x, np.float64)
         _check(lib().smvp_sharded_set_x(self._h, None if keep is None else _p(keep)), "smvp_sharded_set_x")
 
-    def spmv(self, allgather=True, timed=True):
+    def spmv(self, allgather=GATHER_OVERLAPPED, timed=True):
+        """allgather: GATHER_NONE / GATHER_OVERLAPPED (True) / GATHER_AFTER."""
         _check(lib().smvp_sharded_spmv(self._h, int(allgather), int(timed)), "smvp_sharded_spmv")
 
     def feed_back(self, normalize=False):

@@ -730,6 +730,116 @@ def test_single_process_sharded_products(torch, name, ngpus):
         S.close()
 
 
+@pytest.mark.parametrize("chunks,balance", [(1, True), (3, True), (4, False), (7, True)])
+@pytest.mark.parametrize("gather", [sm.GATHER_OVERLAPPED, sm.GATHER_AFTER])
+def test_sharded_chunks_and_both_exchange_forms(torch, chunks, balance, gather):
+    """Row chunks inside a block (each its own handle), entry-balanced bounds padded on the wire, the gathered pieces
+    put back in row order; overlapped and plain exchange.  One GPU here: the chunk / padding / placement logic is
+    what is exercised (the N > 1 exchange itself has only ever run in the gloo tests of the Python layer)."""
+    m, n, coo = load("memplus.mtx")
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    x = np.random.default_rng(3).random(n)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+    scale = row_scale(row_ptr, col_ind, val, x)
+    for fmt in ("csr", "tjds"):
+        S = sm.ShardedMatrix(fmt, 1, m, n, coo=coo, csr=(row_ptr, col_ind, val), chunks=chunks, balance=balance)
+        c, bounds, cb = S.layout()
+        assert c == chunks and bounds.tolist() == [0, m] and cb[0, 0] == 0 and cb[0, -1] == m and np.all(np.diff(cb[0]) >= 0)
+        if balance and chunks > 1:      # memplus: balanced by entries, so the chunks are of unequal height
+            per = np.diff(row_ptr[cb[0]])
+            assert per.max() <= 1.3 * per.mean() and len(set(np.diff(cb[0]).tolist())) > 1
+        S.set_x(x)
+        for _ in range(2):
+            S.spmv(allgather=gather, timed=True)
+            assert S.synchronize() > 0
+        assert_close(S.get_y(0, gathered=True), ref, scale)
+        assert_close(S.get_y(0, gathered=False), ref, scale)
+        S.close()
+
+
+def test_sharded_more_chunks_than_rows_and_tiny_matrices(torch):
+    m, n, coo = load("pdp08-pg4.mtx")                      # 6 x 6
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, np.ones(n))
+    for fmt in ("csr", "tjds"):
+        S = sm.ShardedMatrix(fmt, 1, m, n, coo=coo, csr=(row_ptr, col_ind, val), chunks=16)
+        S.set_x(None)
+        S.spmv()
+        S.synchronize()
+        assert np.array_equal(S.get_y(), ref)
+        S.close()
+
+
+@pytest.mark.skipif(len(_gpu_counts()) < 2, reason="needs at least two GPUs")
+@pytest.mark.parametrize("ngpus", [g for g in _gpu_counts() if g > 1])
+def test_sharded_unequal_blocks_on_several_gpus(torch, ngpus):
+    """rows % ngpus != 0, more GPUs than rows, every slot's gathered y against the host (runs only where N > 1 GPUs exist)."""
+    rng = np.random.default_rng(ngpus)
+    for rows, cols in ((1003, 997), (max(1, ngpus - 1), 5)):
+        lens = rng.integers(0, 9, rows).tolist()
+        lens = [min(l, cols) for l in lens]
+        row_ptr, col_ind, val = csr_from_lengths(rng, lens, cols)
+        coo = sm.make_coo(np.repeat(np.arange(rows), lens), col_ind, val)
+        x = rng.random(cols)
+        ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+        scale = row_scale(row_ptr, col_ind, val, x)
+        for fmt in ("csr", "tjds"):
+            for gather in (sm.GATHER_OVERLAPPED, sm.GATHER_AFTER):
+                S = sm.ShardedMatrix(fmt, ngpus, rows, cols, coo=coo, csr=(row_ptr, col_ind, val), chunks=3)
+                S.set_x(x)
+                S.spmv(allgather=gather)
+                S.synchronize()
+                for slot in range(ngpus):
+                    assert_close(S.get_y(slot, gathered=True), ref, scale)
+                S.close()
+
+
+def test_calls_leave_the_callers_device_alone(torch):
+    """Every entry point that touches a device runs on the handle's device and restores the caller's (hipGetDevice
+    unchanged); with one GPU this can only check that nothing breaks, with several it is the real test."""
+    m, n, coo = load("ibm32.mtx")
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    last = torch.cuda.device_count() - 1
+    before = torch.cuda.current_device()
+    A = sm.CsrMatrix(m, n, row_ptr, col_ind, val, device=last)
+    A.set_kernel(sm.CSR_KERNEL_STREAM, 256)
+    T = sm.TjdsMatrix(sm.tjds_from_coo(coo, m, n), device=last)
+    T.set_mode(sm.TJDS_MODE_TWO_PHASE)
+    T.set_ref_quirks(True)
+    S = sm.ShardedMatrix("csr", torch.cuda.device_count(), m, n, csr=(row_ptr, col_ind, val))
+    S.set_x(None)
+    S.spmv()
+    S.synchronize()
+    S.close()
+    sm.csr_compute(coo, m, n, iters=2, device=last)
+    sm.tjds_compute(coo, m, n, iters=2, device=last)
+    A.close()
+    T.close()
+    assert torch.cuda.current_device() == before
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    dev = ctypes.c_int(-1)
+    assert hip.hipGetDevice(ctypes.byref(dev)) == 0 and dev.value == before
+
+
+def test_set_kernel_rejects_tile_sizes_the_resolved_kernel_lacks(torch):
+    m, n, coo = load("ibm32.mtx")
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    A = sm.CsrMatrix(m, n, row_ptr, col_ind, val)
+    for bad in (512, 100, 4096):
+        with pytest.raises(sm.SmvpError):
+            A.set_kernel(sm.CSR_KERNEL_AUTO, bad)          # AUTO resolves to the stream kernel: 256 / 1024 / 2048 only
+    with pytest.raises(sm.SmvpError):
+        A.set_kernel(sm.CSR_KERNEL_STREAM_CARRY, 256)
+    A.set_kernel(sm.CSR_KERNEL_AUTO, 2048)
+    assert A.get_kernel() == (sm.CSR_KERNEL_STREAM, 2048)
+    x = torch.ones(n, dtype=torch.float64, device="cuda")
+    y = torch.empty(m, dtype=torch.float64, device="cuda")
+    A.spmv(x, y)                                            # still launchable
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy(), ob.csr_spmv(row_ptr, col_ind, val, np.ones(n)))
+
+
 def test_sharded_rejects_bad_gpu_counts(torch):
     m, n, coo = load("ibm32.mtx")
     csr = sm.csr_from_coo(coo, m)
