@@ -90,6 +90,18 @@ def test_csr_sample_matrices_ones(torch, name, kernel, param):
         got = ob.fmt_g(y)
         if name in EXACT:
             assert got == want
+        else:
+            # memplus: the "%g" text of every row the kernel sums in the serial order (one lane, up to 32 entries) and
+            # of every well-conditioned longer row must be the committed report's; only rows whose sum cancels to
+            # less than 1e-6 of its terms may print differently after a re-ordered sum
+            lens = np.diff(row_ptr)
+            scale = row_scale(row_ptr, col_ind, val, x)
+            serial = lens <= (32 if kernel == sm.CSR_KERNEL_STREAM else 0)
+            if kernel == sm.CSR_KERNEL_STREAM_CARRY:      # rows inside one tile are summed by one lane there too
+                serial = (lens <= 32) & (row_ptr[:-1] // param == (np.maximum(row_ptr[1:], 1) - 1) // param)
+            well = np.abs(ref) > 1e-6 * scale
+            assert all(got[i] == want[i] for i in np.flatnonzero(serial))
+            assert sum(got[i] != want[i] for i in np.flatnonzero(well & ~serial)) <= 2    # a last-digit rounding tie at most
 
 
 @pytest.mark.parametrize("name", SAMPLES)
@@ -570,7 +582,7 @@ def test_bench_script_runs_small(torch):
 
     from conftest import ROOT
 
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--copies", "8", "--rows-log2", "16",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--copies", "8", "--rows-log2", "16", "--rows", "300000",
                         "--steps", "5", "--warmup", "2", "--cpu-iters", "2"], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -585,6 +597,12 @@ def test_bench_script_runs_small(torch):
     assert j["extra"]["full_size_parity"]["y_equals_tiled_reference_memplus_y"]
     assert j["cpu_baseline"]["gpu_rows_bit_identical_to_serial"] > 0.98
     assert "error" not in j["extra"]["tjds"] and "error" not in j["extra"]["survey_random_model"]
+    assert "substitute" in j["config"]["workload"]
+    c4, pw = j["extra"]["config4"], j["extra"]["pwt_tiled"]
+    assert "error" not in c4 and c4["n_gpus"] == 1 and c4["rows"] == 300000 and c4["nnz"] == 32 * 300000 and c4["spmv_only_ms"] > 0
+    assert "error" not in pw and pw["y_equals_tiled_reference_pwt_y"] and pw["tjds"]["equals_csr_bit_for_bit"]
+    sm_ = j["extra"]["sample_matrices"]["memplus.mtx"]
+    assert sm_["csr_avg_ms"] < sm_["csr_avg_ms_event_pairs"] and sm_["csr_agrees_with_cpu"] and sm_["tjds_agrees_with_cpu"]
 
 
 # --------------------------------------------------- device-side format conversion
@@ -1055,6 +1073,31 @@ def test_config4_full_size_properties(torch):
     k = 20_000
     ref = ob.csr_spmv(row_ptr[:k + 1].copy(), col_ind[:row_ptr[k]], val[:row_ptr[k]], xa.cpu().numpy())
     assert np.array_equal(ya.cpu().numpy()[:k], ref)        # 32 entries per row: one lane, serial order, same bits
+    A.close()
+
+
+@pytest.mark.parametrize("name", SAMPLES)
+def test_device_built_arrays_against_committed_golden_arrays(torch, name):
+    """COO -> CSR / TJDS on the GPU, compared directly with tests/golden/arrays/*.npz (not via the host converters):
+    row_ptr, col_ind, perm, start_pos, row_ind bit for bit, and the quirk scalars."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "arrays", name.replace(".mtx", ".npz")))
+    m, n, coo = load(name)
+    rng = np.random.default_rng(4)
+    d_coo = _coo_to_device(torch, coo[rng.permutation(len(coo))])          # any input order
+    rp, ci, v = sm.csr_from_coo_device(d_coo, m, n, len(coo))
+    assert np.array_equal(rp.cpu().numpy(), g["row_ptr"]) and np.array_equal(ci.cpu().numpy(), g["col_ind"])
+    t = sm.tjds_from_coo_device(d_coo, m, n, len(coo))
+    for f in ("perm", "start_pos", "row_ind"):
+        assert np.array_equal(getattr(t, f).cpu().numpy(), g[f]), f
+    assert (t.num_diag, t.ref_num_tjdiag, t.last_diag_single) == \
+        (int(g["num_diag"]), int(g["ref_num_tjdiag"]), int(g["last_diag_single"]))
+    # and the values travel with their indices: the product of the device-built arrays is the golden vector
+    A = sm.CsrMatrix(m, n, rp, ci, v)
+    dy = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+    A.spmv(torch.ones(n, dtype=torch.float64, device="cuda"), dy)
+    torch.cuda.synchronize()
+    lens = np.diff(g["row_ptr"])
+    assert np.array_equal(dy.cpu().numpy()[lens <= 32], g["y_csr"][lens <= 32])
     A.close()
 
 
