@@ -93,6 +93,24 @@ int smvp_mm_read_header_path(const char *path, smvp_mm_typecode *matcode, int *r
 int smvp_mm_read_coo_path(const char *path, smvp_coo_t *out, int capacity,
                           smvp_mm_typecode *matcode, int *rows, int *cols, int *nnz);
 
+/* Optional, NOT what the reference does (main-cli.c:1427-1441 multiplies the stored triangle of a symmetric file as it
+ * stands, and so does everything here by default): mirror the off-diagonal entries of symmetric / hermitian (real) /
+ * skew-symmetric storage so that the full matrix is multiplied.  General files are copied.  `out` may not alias `coo`. */
+int smvp_mm_expanded_count(const smvp_mm_typecode matcode, const smvp_coo_t *coo, int nnz, int *count);
+int smvp_mm_expand_symmetric(const smvp_mm_typecode matcode, const smvp_coo_t *coo, int nnz, int rows, int cols,
+                             smvp_coo_t *out, int capacity, int *nnz_out);
+
+/* Binary cache of a loaded matrix (new: the reference parses the text on every run): CSR arrays behind a header that
+ * names the .mtx they were made from -- its size and the FNV-1a 64 of its bytes -- plus a checksum of the arrays.
+ * flags bit 0 = symmetric storage was expanded.  smvp_cache_read_header fails with SMVP_ERR_IO when there is no
+ * cache and with SMVP_ERR_INVALID when the file is not one, or was made from other bytes than mtx_path now holds. */
+int smvp_cache_write_csr(const char *cache_path, const char *mtx_path, const smvp_mm_typecode matcode, int flags,
+                         int rows, int cols, int nnz, const int *row_ptr, const int *col_ind, const double *val);
+int smvp_cache_read_header(const char *cache_path, const char *mtx_path, smvp_mm_typecode *matcode, int *flags,
+                           int *rows, int *cols, int *nnz);
+int smvp_cache_read_csr(const char *cache_path, int rows, int nnz, int *row_ptr, int *col_ind, double *val);
+int smvp_coo_from_csr(int rows, const int *row_ptr, const int *col_ind, const double *val, smvp_coo_t *out);
+
 /* ------------------------------------------------------- format conversion */
 /* Replaces the CSR build inside smvp_csr_compute, main-cli.c:340-365.
  * row_ptr[rows+1], col_ind[nnz], val[nnz]; entries ordered by (row, col) with
@@ -297,6 +315,15 @@ int smvp_generate_report_text(const char *input_file_name, const char *report_di
                               const char *alg_name, int nnz, int rows, int iters,
                               const double *y, const smvp_time_stats_t *stats,
                               unsigned long unix_time, char *out_path, size_t out_path_cap);
+
+/* ------------------------------------------------------------- CISR export */
+/* Replaces  void smvp_cisr_coegen(MMRawData*, int rows, int nnz, int slotCount)   main-cli.c:473-729
+ * (-g / --cisr-gen, -s / --slots): the matrix dealt row by row onto `slots` channels and written as a Xilinx Vivado
+ * .coe block-RAM image -- the reference prints it to stdout, here it goes to `out`.  Host only (no GPU).  Returns
+ * SMVP_ERR_UNSUPPORTED where the reference prints "slot_group_iter overran fInputNonZeros!" and exits
+ * (main-cli.c:596-600; always with one slot).  Parity unpinned: the reference holds no .coe output. */
+int smvp_cisr_coegen(const smvp_coo_t *coo, int rows, int nnz, int slots, FILE *out);
+int smvp_cisr_coegen_path(const smvp_coo_t *coo, int rows, int nnz, int slots, const char *path);
 
 /* ------------------------------------------------------ synthetic workloads */
 /* SURVEY 8(d) / BASELINE.json configs: matrices generated straight into CSR,

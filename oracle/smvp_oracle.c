@@ -524,3 +524,106 @@ void orc_tjds_timed(int rows, int cols, int num_diag, const int *perm, const int
     }
     free(xp);
 }
+
+/* ---------------------------------------------------------------------------
+ * CISR .coe generator: main-cli.c:473-729 (smvp_cisr_coegen).  PARITY UNPINNED:
+ * the reference holds no .coe output and main-cli.c cannot be built here
+ * (libpopt), so nothing but a reading of the source checks this restatement.
+ *
+ * It keeps the reference's structure: the whole slot-group table first
+ * (:524-607), then the value records (:624-648), then the packed words
+ * (:689-728).  Returns 0, or 1 where the reference prints "slot_group_iter
+ * overran fInputNonZeros!" and exits (:603-607) -- which it does for every
+ * matrix when there is a single slot.  row_ptr is the standard prefix sum; the
+ * reference's own is undefined for matrices with empty rows (:497-512).
+ * ------------------------------------------------------------------------- */
+int orc_cisr_coegen(const orc_coo *coo_in, int rows, int nnz, int slots, FILE *out)
+{
+    int *row_ptr = (int *)malloc(sizeof(int) * ((size_t)rows + 1));
+    int *col_ind = (int *)malloc(sizeof(int) * (size_t)(nnz ? nnz : 1));
+    double *val = (double *)malloc(sizeof(double) * (size_t)(nnz ? nnz : 1));
+    int *row_len = (int *)calloc((size_t)rows + 1, sizeof(int));
+    orc_csr_build(coo_in, rows, nnz, row_ptr, col_ind, val);
+
+    /* worst case one group per entry (+1): the reference allocates nnz groups and bails out beyond */
+    int *grp = (int *)malloc(sizeof(int) * (size_t)slots * ((size_t)nnz + 2));
+    int *row_end = (int *)calloc((size_t)slots, sizeof(int));
+    int g = 0, next_row = 0, eof = 0, rc = 0;
+    while (!eof) {
+        for (int s = 0; s < slots; ++s) {
+            int *cur = &grp[(size_t)g * slots + s];
+            if (g == 0 || grp[(size_t)(g - 1) * slots + s] >= row_end[s] - 1) { /* :534 first group / :559 row used up */
+                if (next_row < rows) {                                           /* :539, :569 */
+                    *cur = row_ptr[next_row];
+                    row_end[s] = row_ptr[next_row + 1];
+                    row_len[next_row] = row_ptr[next_row + 1] - row_ptr[next_row];
+                    ++next_row;
+                } else {
+                    *cur = row_ptr[rows] + 1; /* :549, :565 "invalid index" */
+                }
+            } else {
+                *cur = grp[(size_t)(g - 1) * slots + s] + 1; /* :580 */
+            }
+        }
+        eof = 1; /* :586-591 */
+        for (int s = 0; s < slots; ++s)
+            if (grp[(size_t)g * slots + s] < nnz)
+                eof = 0;
+        ++g;
+        if (g >= nnz) { /* :596-600 */
+            rc = 1;
+            break;
+        }
+    }
+    if (rc == 0) {
+        const int words = g * slots;
+        fprintf(out, "\n;*********************************************");
+        fprintf(out, "\n;* CISR COE File for Vivado Single-Port BRAM *");
+        fprintf(out, "\n;*********************************************\n");
+        fprintf(out, "\n;Generated with a slot/channel count of: %d\n\n", slots);
+        fprintf(out, "memory_initialization_radix=16;\n");
+        fprintf(out, "memory_initialization_vector=\n");
+        fprintf(out, "00%08x,\n", 0xAAAAAAAAu);
+        int rl = 0;
+        for (int w = 0; w < words; ++w) {
+            const int idx = grp[w], slot = w % slots;
+            double v = 0.0;
+            int c = 0;
+            if (idx < nnz) { /* :631-645: padding is value 0, column 0 */
+                v = val[idx];
+                c = col_ind[idx];
+            }
+            /* :703 ((int)val << 20) | (col << 8) | slot, printed with %08x: the low 32 bits */
+            const int iv = (v >= -2147483648.0 && v < 2147483648.0) ? (int)v : (int)0x80000000u;
+            unsigned word = ((unsigned)iv << 20) | ((unsigned)c << 8) | (unsigned)slot;
+            fprintf(out, "01%08x,\n", word);
+            if (rl < rows) { /* :707-726 two row lengths per word while any remain */
+                word = (1u << 28) | ((unsigned)row_len[rl] << 16);
+                ++rl;
+                if (rl < rows) {
+                    word |= (1u << 12) | (unsigned)row_len[rl];
+                    ++rl;
+                }
+                fprintf(out, "02%08x,\n", word);
+            }
+        }
+        fprintf(out, "03%08x;\n\n", 0xFFFFFFFFu);
+    }
+    free(grp);
+    free(row_end);
+    free(row_len);
+    free(row_ptr);
+    free(col_ind);
+    free(val);
+    return rc;
+}
+
+int orc_cisr_coegen_path(const orc_coo *coo, int rows, int nnz, int slots, const char *path)
+{
+    FILE *f = fopen(path, "w");
+    if (!f)
+        return -1;
+    const int rc = orc_cisr_coegen(coo, rows, nnz, slots, f);
+    fclose(f);
+    return rc;
+}

@@ -16,6 +16,8 @@
 #ifndef SMVP_ORACLE_H
 #define SMVP_ORACLE_H
 
+#include <stdio.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -84,6 +86,11 @@ void orc_csr_timed(int rows, const int *row_ptr, const int *col_ind, const doubl
 void orc_tjds_timed(int rows, int cols, int num_diag, const int *perm, const int *start_pos,
                     const int *row_ind, const double *val, const double *x, double *y,
                     int iters, double *ms_each);
+
+/* CISR .coe generator, main-cli.c:473-729 (PARITY UNPINNED: no reference output exists).  0 = written,
+ * 1 = the reference's "slot_group_iter overran" exit. */
+int orc_cisr_coegen(const orc_coo *coo, int rows, int nnz, int slots, FILE *out);
+int orc_cisr_coegen_path(const orc_coo *coo, int rows, int nnz, int slots, const char *path);
 
 #ifdef __cplusplus
 }

@@ -15,12 +15,12 @@
  *   - without -d the report goes to the current directory (the reference reads
  *     an uninitialised pointer, main-cli.c:1223,1458).
  *   - TJDS is the corrected product unless --ref-quirks is given.
- *   - -g / -s (CISR .coe generation for an FPGA, main-cli.c:473-729) are
- *     recognised and refused: out of scope for the GPU engine.
+ *   - -g / -s (CISR .coe generation, main-cli.c:473-729) print the .coe image to stdout like the
+ *     reference (host-only work, no GPU; --all-algs stays CSR + TJDS).
  *   - libpopt is not used (absent from the image): getopt_long("+...") gives the
  *     same POSIX ordering rule.
  * Additive flags: --device N, --gpus N, --iterate, --normalize, --ref-quirks, --device-convert, --csr-kernel auto|vector|stream|stream-carry,
- * --tjds-mode auto|row-gather|two-phase|atomic, --timing auto|events|device,
+ * --tjds-mode auto|row-gather|two-phase|atomic, --timing auto|events|device, --expand-symmetric, --cache,
  * --quiet-arrays is implied (the reference's SMVP_CSR_DEBUG array dumps,
  * main-cli.c:374-394, are not printed).
  */
@@ -44,7 +44,7 @@
 
 enum { ALG_NONE = 0, ALG_CSR = 1 << 1, ALG_TJDS = 1 << 2, ALG_CISR = 1 << 3, ALG_ALL = 256 };
 enum { OPT_DEVICE = 1000, OPT_QUIRKS, OPT_KERNEL, OPT_USAGE, OPT_DEVCONV, OPT_GPUS, OPT_ITERATE, OPT_NORMALIZE, OPT_TIMING,
-       OPT_TJDS_MODE };
+       OPT_TJDS_MODE, OPT_EXPAND, OPT_CACHE };
 
 static void usage(FILE *to, const char *prog)
 {
@@ -53,6 +53,7 @@ static void usage(FILE *to, const char *prog)
             "        [-n|--number=1000] [-s|--slots=16] [-d|--dir=./] [--device=0] [--gpus=1]\n"
             "        [--ref-quirks] [--iterate] [--normalize] [--device-convert] [--csr-kernel=auto|vector|stream|stream-carry]\n"
             "        [--tjds-mode=auto|row-gather|two-phase|atomic] [--timing=auto|events|device]\n"
+            "        [--expand-symmetric] [--cache]\n"
             "        [-?|--help] [--usage]\n"
             "        [OPTIONS] <file>\n",
             prog);
@@ -77,6 +78,8 @@ static void help(const char *prog)
     puts("      --csr-kernel=auto    CSR kernel family: auto, vector, stream, stream-carry.");
     puts("      --tjds-mode=auto     TJDS product: auto (= row-gather, one kernel), two-phase, atomic.");
     puts("      --timing=auto        Per-product window: events (hipEvent pair), device (the kernel times itself), auto.");
+    puts("      --expand-symmetric   Mirror the stored triangle of a symmetric file (the reference multiplies it as stored).");
+    puts("      --cache              Keep / use <file>.smvpbin, a binary copy of the loaded matrix tied to the file's checksum.");
     puts("\nHelp options:");
     puts("  -?, --help               Show this help message");
     puts("      --usage              Display brief usage message");
@@ -157,11 +160,12 @@ int main(int argc, char *argv[])
         {"device-convert", no_argument, NULL, OPT_DEVCONV}, {"gpus", required_argument, NULL, OPT_GPUS},
         {"iterate", no_argument, NULL, OPT_ITERATE}, {"normalize", no_argument, NULL, OPT_NORMALIZE},
         {"timing", required_argument, NULL, OPT_TIMING}, {"tjds-mode", required_argument, NULL, OPT_TJDS_MODE},
+        {"expand-symmetric", no_argument, NULL, OPT_EXPAND}, {"cache", no_argument, NULL, OPT_CACHE},
         {NULL, 0, NULL, 0}};
     const char *prog = "smvp-toolkit-cli";
     int alg_mode = ALG_NONE, calc_iter = 1000, cisr_slots = 16, device = 0, quirks = 0;
     int csr_kernel = SMVP_CSR_KERNEL_AUTO, device_convert = 0, ngpus = 1, iterate = 0, normalize = 0;
-    int timing = SMVP_TIMING_AUTO, tjds_mode = SMVP_TJDS_MODE_AUTO;
+    int timing = SMVP_TIMING_AUTO, tjds_mode = SMVP_TJDS_MODE_AUTO, expand = 0, use_cache = 0;
     const char *report_dir = "";
 
     if (argc < 2) { /* main-cli.c:1267-1271 */
@@ -266,6 +270,12 @@ int main(int argc, char *argv[])
             else
                 die("Unknown TJDS product form (use auto, row-gather, two-phase or atomic).");
             break;
+        case OPT_EXPAND:
+            expand = 1;
+            break;
+        case OPT_CACHE:
+            use_cache = 1;
+            break;
         case OPT_USAGE:
             usage(stdout, prog);
             return 0;
@@ -287,7 +297,6 @@ int main(int argc, char *argv[])
             return 1;
         }
     }
-    (void)cisr_slots;
 
     /* exactly one positional argument, main-cli.c:1389-1393 */
     if (optind != argc - 1) {
@@ -318,16 +327,78 @@ int main(int argc, char *argv[])
     if (rows < 0 || cols < 0 || nnz < 0)
         mmio_fail(SMVP_MM_UNSUPPORTED_TYPE);
 
-    smvp_coo_t *coo = malloc(sizeof *coo * (size_t)(nnz > 0 ? nnz : 1)); /* heap, not a stack VLA (main-cli.c:1426) */
-    double *y = malloc(sizeof *y * (size_t)(rows > 0 ? rows : 1));
-    double *each = malloc(sizeof *each * (size_t)calc_iter);
-    if (!coo || !y || !each)
-        die("Out of memory while staging the matrix.");
-    rc = smvp_mm_read_coo_entries(f, tc, nnz, coo);
-    if (rc != SMVP_OK)
-        mmio_fail(rc);
+    /* --cache: <file>.smvpbin, valid only for the present bytes of <file> and for the same --expand-symmetric choice */
+    char *cache_path = NULL;
+    int cached = 0;
+    smvp_coo_t *coo = NULL;
+    if (use_cache) {
+        cache_path = malloc(strlen(input) + 16);
+        if (!cache_path)
+            die("Out of memory while staging the matrix.");
+        sprintf(cache_path, "%s.smvpbin", input);
+        smvp_mm_typecode ctc;
+        int cflags = 0, cr = 0, cc = 0, cn = 0;
+        if (smvp_cache_read_header(cache_path, input, &ctc, &cflags, &cr, &cc, &cn) == SMVP_OK && cr == rows && cc == cols &&
+            (cflags & 1) == expand) {
+            int *rp = malloc(sizeof *rp * ((size_t)cr + 1)), *ci = malloc(sizeof *ci * (size_t)(cn > 0 ? cn : 1));
+            double *cv = malloc(sizeof *cv * (size_t)(cn > 0 ? cn : 1));
+            coo = malloc(sizeof *coo * (size_t)(cn > 0 ? cn : 1));
+            if (!rp || !ci || !cv || !coo)
+                die("Out of memory while staging the matrix.");
+            if (smvp_cache_read_csr(cache_path, cr, cn, rp, ci, cv) == SMVP_OK && smvp_coo_from_csr(cr, rp, ci, cv, coo) == SMVP_OK) {
+                cached = 1;
+                nnz = cn;
+                printf(YELLOW "[INFO]\tMatrix content taken from the binary cache %s\n" RESET, cache_path);
+            } else {
+                free(coo);
+                coo = NULL;
+            }
+            free(rp);
+            free(ci);
+            free(cv);
+        }
+    }
+    if (!cached) {
+        coo = malloc(sizeof *coo * (size_t)(nnz > 0 ? nnz : 1)); /* heap, not a stack VLA (main-cli.c:1426) */
+        if (!coo)
+            die("Out of memory while staging the matrix.");
+        rc = smvp_mm_read_coo_entries(f, tc, nnz, coo);
+        if (rc != SMVP_OK)
+            mmio_fail(rc);
+        if (expand) { /* not the reference's behaviour: it multiplies the stored triangle (main-cli.c:1427-1441) */
+            int full = 0;
+            rc = smvp_mm_expanded_count(tc, coo, nnz, &full);
+            smvp_coo_t *all = rc == SMVP_OK ? malloc(sizeof *all * (size_t)(full > 0 ? full : 1)) : NULL;
+            if (rc != SMVP_OK || !all)
+                engine_fail("Expanding the symmetric storage", rc != SMVP_OK ? rc : SMVP_ERR_ALLOC);
+            rc = smvp_mm_expand_symmetric(tc, coo, nnz, rows, cols, all, full, &full);
+            if (rc != SMVP_OK)
+                engine_fail("Expanding the symmetric storage", rc);
+            printf(YELLOW "[INFO]\tSymmetric storage expanded: %d stored entries -> %d.\n" RESET, nnz, full);
+            free(coo);
+            coo = all;
+            nnz = full;
+        }
+        if (use_cache) {
+            int *rp = malloc(sizeof *rp * ((size_t)rows + 1)), *ci = malloc(sizeof *ci * (size_t)(nnz > 0 ? nnz : 1));
+            double *cv = malloc(sizeof *cv * (size_t)(nnz > 0 ? nnz : 1));
+            if (rp && ci && cv && smvp_csr_from_coo(coo, rows, nnz, rp, ci, cv) == SMVP_OK &&
+                smvp_cache_write_csr(cache_path, input, tc, expand, rows, cols, nnz, rp, ci, cv) == SMVP_OK)
+                printf(MAGENTA "[FILE]\tBinary cache written: " RESET "%s\n", cache_path);
+            else
+                printf(YELLOW "[INFO]\tBinary cache not written: %s\n" RESET, smvp_last_error());
+            free(rp);
+            free(ci);
+            free(cv);
+        }
+    }
+    free(cache_path);
     if (f != stdin)
         fclose(f);
+    double *y = malloc(sizeof *y * (size_t)(rows > 0 ? rows : 1));
+    double *each = malloc(sizeof *each * (size_t)calc_iter);
+    if (!y || !each)
+        die("Out of memory while staging the matrix.");
 
     printf(CYAN "[DATA]\tNon-zero numbers contained in matrix: " RESET "%d\n", nnz);
     printf(CYAN "[DATA]\tVector operand in use: " RESET "Ones vector with dimensions [%d, %d]\n", rows, 1);
@@ -335,8 +406,6 @@ int main(int argc, char *argv[])
         printf(CYAN "[DATA]\tPower iteration: " RESET "each result is the next operand%s\n",
                normalize ? ", scaled to largest magnitude 1" : "");
 
-    if (alg_mode & ALG_CISR)
-        die("CISR COE generation targets an FPGA flow and is not part of the MI355X engine.");
 
     const int run_csr = (alg_mode == ALG_ALL) || (alg_mode & ALG_CSR);
     const int run_tjds = (alg_mode == ALG_ALL) || (alg_mode & ALG_TJDS);
@@ -392,6 +461,17 @@ int main(int argc, char *argv[])
         printf(MAGENTA "[FILE]\tExecution report file saved as:\n" RESET);
         printf("\t%s\n", path);
         print_rates("TJDS", rows, cols, nnz, 0, &st);
+    }
+
+    if (alg_mode != ALG_ALL && (alg_mode & ALG_CISR)) { /* main-cli.c:1473-1476; host only.  --all-algs = CSR + TJDS */
+        printf(YELLOW "[INFO]\tConverting loaded content to CISR format.\n" RESET);
+        rc = smvp_cisr_coegen(coo, rows, nnz, cisr_slots, stdout);
+        if (rc == SMVP_ERR_UNSUPPORTED) { /* the reference's own exit, main-cli.c:596-600 */
+            printf("\n[ERROR]\tslot_group_iter overran fInputNonZeros!\n");
+            return 1;
+        }
+        if (rc != SMVP_OK)
+            engine_fail("CISR COE generation", rc);
     }
 
     free(each);

@@ -63,7 +63,8 @@ _lib = None
 EXPORTS = [
     "smvp_last_error", "smvp_version_string",
     "smvp_mm_read_banner", "smvp_mm_read_mtx_crd_size", "smvp_mm_read_coo_entries",
-    "smvp_mm_read_header_path", "smvp_mm_read_coo_path",
+    "smvp_mm_read_header_path", "smvp_mm_read_coo_path", "smvp_mm_expanded_count", "smvp_mm_expand_symmetric",
+    "smvp_cache_write_csr", "smvp_cache_read_header", "smvp_cache_read_csr", "smvp_coo_from_csr",
     "smvp_csr_from_coo", "smvp_tjds_from_coo", "smvp_csr_from_coo_device", "smvp_tjds_from_coo_device",
     "smvp_device_count", "smvp_device_info",
     "smvp_csr_create", "smvp_csr_set_kernel", "smvp_csr_get_kernel", "smvp_csr_spmv",
@@ -74,7 +75,7 @@ EXPORTS = [
     "smvp_tjds_sharded_create_ex", "smvp_sharded_layout", "smvp_sharded_set_x", "smvp_sharded_spmv",
     "smvp_sharded_synchronize", "smvp_sharded_feed_back", "smvp_sharded_get_y", "smvp_sharded_info", "smvp_sharded_destroy",
     "smvp_run_opts_default", "smvp_csr_compute", "smvp_tjds_compute", "smvp_last_run_info",
-    "smvp_time_stats", "smvp_generate_report_text",
+    "smvp_time_stats", "smvp_generate_report_text", "smvp_cisr_coegen", "smvp_cisr_coegen_path",
     "smvp_synth_row_lengths", "smvp_synth_fill", "smvp_partition_rows",
 ]
 
@@ -141,6 +142,13 @@ def lib():
         L.smvp_partition_rows.argtypes = [vp, ci, ci, vp]
         L.smvp_mm_read_header_path.argtypes = [C.c_char_p, vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
         L.smvp_mm_read_coo_path.argtypes = [C.c_char_p, vp, ci, vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+        L.smvp_mm_expanded_count.argtypes = [vp, vp, ci, C.POINTER(ci)]
+        L.smvp_mm_expand_symmetric.argtypes = [vp, vp, ci, ci, ci, vp, ci, C.POINTER(ci)]
+        L.smvp_cache_write_csr.argtypes = [C.c_char_p, C.c_char_p, vp, ci, ci, ci, ci, vp, vp, vp]
+        L.smvp_cache_read_header.argtypes = [C.c_char_p, C.c_char_p, vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+        L.smvp_cache_read_csr.argtypes = [C.c_char_p, ci, ci, vp, vp, vp]
+        L.smvp_coo_from_csr.argtypes = [ci, vp, vp, vp, vp]
+        L.smvp_cisr_coegen_path.argtypes = [vp, ci, ci, ci, C.c_char_p]
         L.smvp_device_count.argtypes = [C.POINTER(ci)]
         L.smvp_device_info.argtypes = [ci, C.c_char_p, C.c_size_t, C.POINTER(ci), C.POINTER(C.c_size_t)]
         _lib = L
@@ -180,6 +188,55 @@ def mm_read_coo(path):
     _check(lib().smvp_mm_read_coo_path(os.fsencode(path), _p(coo), nz, C.cast(tcb, C.c_void_p), C.byref(mm),
                                        C.byref(nn), C.byref(nzz)), "smvp_mm_read_coo_path")
     return tcb.raw.decode(), mm.value, nn.value, coo[:nz]
+
+
+def mm_expand_symmetric(typecode, coo, rows, cols):
+    """Mirror the off-diagonal entries of symmetric / skew-symmetric storage (NOT the reference's behaviour) -> coo."""
+    nnz = len(coo)
+    coo = _arr(coo, COO_DTYPE)
+    tc = C.create_string_buffer(typecode.encode()[:4].ljust(4), 4)
+    want = C.c_int()
+    _check(lib().smvp_mm_expanded_count(C.cast(tc, C.c_void_p), _p(coo), nnz, C.byref(want)), "smvp_mm_expanded_count")
+    out = np.zeros(max(want.value, 1), dtype=COO_DTYPE)
+    got = C.c_int()
+    _check(lib().smvp_mm_expand_symmetric(C.cast(tc, C.c_void_p), _p(coo), nnz, rows, cols, _p(out), want.value,
+                                          C.byref(got)), "smvp_mm_expand_symmetric")
+    return out[:got.value]
+
+
+def cache_write_csr(cache_path, mtx_path, typecode, rows, cols, row_ptr, col_ind, val, expanded=False):
+    rp, ci, v = _arr(row_ptr, np.int32), _arr(col_ind, np.int32), _arr(val, np.float64)
+    tc = C.create_string_buffer(typecode.encode()[:4].ljust(4), 4)
+    _check(lib().smvp_cache_write_csr(os.fsencode(cache_path), os.fsencode(mtx_path), C.cast(tc, C.c_void_p), int(expanded),
+                                      rows, cols, int(rp[rows]), _p(rp), _p(ci), _p(v)), "smvp_cache_write_csr")
+
+
+def cache_read_csr(cache_path, mtx_path=None):
+    """-> (typecode, expanded, rows, cols, row_ptr, col_ind, val); raises SmvpError (ERR_IO: no cache, ERR_INVALID: stale)."""
+    tc = C.create_string_buffer(4)
+    fl, m, n, nz = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    _check(lib().smvp_cache_read_header(os.fsencode(cache_path), None if mtx_path is None else os.fsencode(mtx_path),
+                                        C.cast(tc, C.c_void_p), C.byref(fl), C.byref(m), C.byref(n), C.byref(nz)),
+           "smvp_cache_read_header")
+    rp = np.zeros(m.value + 1, dtype=np.int32)
+    ci = np.zeros(max(nz.value, 1), dtype=np.int32)
+    v = np.zeros(max(nz.value, 1), dtype=np.float64)
+    _check(lib().smvp_cache_read_csr(os.fsencode(cache_path), m.value, nz.value, _p(rp), _p(ci), _p(v)), "smvp_cache_read_csr")
+    return tc.raw.decode(), bool(fl.value & 1), m.value, n.value, rp, ci[:nz.value], v[:nz.value]
+
+
+def coo_from_csr(rows, row_ptr, col_ind, val):
+    rp, ci, v = _arr(row_ptr, np.int32), _arr(col_ind, np.int32), _arr(val, np.float64)
+    out = np.zeros(max(int(rp[rows]), 1), dtype=COO_DTYPE)
+    _check(lib().smvp_coo_from_csr(rows, _p(rp), _p(ci), _p(v), _p(out)), "smvp_coo_from_csr")
+    return out[:int(rp[rows])]
+
+
+def cisr_coegen(coo, rows, slots, path):
+    """CISR .coe file of the matrix (smvp_cisr_coegen_path); raises SmvpError (ERR_UNSUPPORTED: the reference's overrun exit)."""
+    n = len(coo)
+    _check(lib().smvp_cisr_coegen_path(_p(_arr(coo, COO_DTYPE)), rows, n, slots, os.fsencode(path)), "smvp_cisr_coegen_path")
+    return open(path).read()
 
 
 def make_coo(rows_idx, cols_idx, vals):

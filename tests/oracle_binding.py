@@ -205,6 +205,14 @@ def tjds_timed(t, x, iters):
     return y, ms
 
 
+def cisr_coegen(coo, rows, slots, path):
+    """Oracle restatement of main-cli.c:473-729 -> (0 written | 1 the reference's overrun exit, text)."""
+    coo = np.ascontiguousarray(coo)
+    lib().orc_cisr_coegen_path.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    rc = lib().orc_cisr_coegen_path(_p(coo if len(coo) else np.zeros(1, dtype=COO_DTYPE)), rows, len(coo), slots, path.encode())
+    return rc, open(path).read()
+
+
 def fmt_g(y):
     """'%g' of every element, through C printf (what main-cli.c:308 prints)."""
     libc = C.CDLL(None)

@@ -858,6 +858,32 @@ def test_set_kernel_rejects_tile_sizes_the_resolved_kernel_lacks(torch):
     assert np.array_equal(y.cpu().numpy(), ob.csr_spmv(row_ptr, col_ind, val, np.ones(n)))
 
 
+def test_expanded_symmetric_product_on_the_gpu(torch, tmp_path):
+    """--expand-symmetric (not the reference's behaviour): A_full . 1 for pwt, CSR and TJDS, against numpy on the
+    fixture; and through the CLI, whose default run must still print the reference's stored-triangle report."""
+    tc, m, n, coo = sm.mm_read_coo(ob.fixture_path("pwt.mtx"))
+    full = sm.mm_expand_symmetric(tc, coo, m, n)
+    want = np.zeros(m)
+    np.add.at(want, coo["row"], coo["val"])
+    off = coo["row"] != coo["col"]
+    np.add.at(want, coo["col"][off], coo["val"][off])
+    y, _, _ = sm.csr_compute(full, m, n, iters=2)
+    assert np.array_equal(y, want)                     # 0/1 matrix: small integers, exact in any order
+    y, _, _ = sm.tjds_compute(full, m, n, iters=2)
+    assert np.array_equal(y, want)
+    p = subprocess.run([sm.CLI_PATH, "-c", "-n", "3", "-d", str(tmp_path), "--expand-symmetric", "--cache",
+                        ob.fixture_path("pwt.mtx")], capture_output=True, text=True, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stdout[-1500:]
+    rep = [f for f in os.listdir(tmp_path) if f.startswith("smvp-toolbox_report_CSR_")]
+    lines = open(os.path.join(tmp_path, rep[0])).read().split("\n")
+    assert lines[lines.index("[") + 1:lines.index("]")] == ob.fmt_g(want)
+    assert "Non-zero numbers contained in matrix: 326107" in lines
+    try:
+        os.remove(ob.fixture_path("pwt.mtx") + ".smvpbin")
+    except OSError:
+        pass
+
+
 def test_sharded_rejects_bad_gpu_counts(torch):
     m, n, coo = load("ibm32.mtx")
     csr = sm.csr_from_coo(coo, m)
