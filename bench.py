@@ -56,8 +56,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="memplus_tiled", choices=["memplus_tiled", "memplus_shaped", "uniform32"])
-    ap.add_argument("--copies", type=int, default=944, help="memplus_tiled: diagonal blocks (944 -> 16.76 M rows)")
+    ap.add_argument("--workload", default="memplus_tiled", choices=["memplus_tiled", "pwt_tiled", "memplus_shaped", "uniform32"])
+    ap.add_argument("--copies", type=int, default=0, help="memplus_tiled / pwt_tiled: diagonal blocks (0 = 944 / 459 -> 16.76 M rows)")
     ap.add_argument("--rows-log2", type=int, default=24, help="memplus_shaped: total rows = 2^k")
     ap.add_argument("--rows", type=int, default=10_000_000, help="uniform32: total rows (BASELINE config 4)")
     ap.add_argument("--format", default="csr", choices=["csr", "tjds"],
@@ -139,18 +139,22 @@ def report_y_lines(name):
 def build_block(sm, sharding, workload, args, rank, world):
     """This rank's row block of the workload -> dict with host CSR arrays and a description."""
     t0 = time.perf_counter()
-    if workload == "memplus_tiled":
-        tc, m, n, coo = sm.mm_read_coo(golden_file("sample-data", "memplus.mtx"))
+    if workload in ("memplus_tiled", "pwt_tiled"):
+        base_name, base_report, base_copies = (("memplus.mtx", "smvp-toolbox_report_CSR_1615284663.txt", 944) if workload == "memplus_tiled"
+                                               else ("pwt.mtx", "smvp-toolbox_report_CSR_1615284671.txt", 459))
+        tc, m, n, coo = sm.mm_read_coo(golden_file("sample-data", base_name))
         rp, ci, v = sm.csr_from_coo(coo, m)
-        total = args.copies * (world if getattr(args, "scaling", "strong") == "weak" else 1)
+        total = (getattr(args, "copies", 0) or base_copies) * (world if getattr(args, "scaling", "strong") == "weak" else 1)
         copies = total - total % world if total >= world else world
         c0, c1 = copies * rank // world, copies * (rank + 1) // world
         row_ptr, col_ind, val = sharding.tile_block_diagonal(rp, ci, v, n, c0, c1)
         blk = dict(rows_total=m * copies, cols_total=n * copies, r0=m * c0, r1=m * c1,
                    bounds=np.array([m * (copies * g // world) for g in range(world + 1)], dtype=np.int64),
-                   name="memplus.mtx x%d block-diagonal (kron(I_%d, memplus)) -- the exact-structure substitute for the "
-                        "SURVEY 8(d) random memplus-shaped model, which is in extra.survey_random_model" % (copies, copies),
-                   base=(m, n, rp, ci, v, c1 - c0))
+                   name=("memplus.mtx x%d block-diagonal (kron(I_%d, memplus)) -- the exact-structure substitute for the "
+                         "SURVEY 8(d) random memplus-shaped model, which is in extra.survey_random_model" % (copies, copies))
+                   if workload == "memplus_tiled" else
+                   "pwt.mtx x%d block-diagonal (kron(I_%d, pwt), stored triangle only like the reference)" % (copies, copies),
+                   base=(m, n, rp, ci, v, c1 - c0, base_report))
     else:
         if workload == "memplus_shaped":
             kind, seed, param = sm.SYNTH_MEMPLUS_SHAPED, 12345, 0
@@ -241,22 +245,22 @@ def measure_csr(torch, dist, sm, sharding_mod, blk, args, world, local_rank, ran
         # full-size parity against the reference's own golden vector: y must be tile(y_memplus), and y_memplus is
         # printed with "%g" in the committed report output-test/smvp-toolbox_report_CSR_1615284663.txt.  No oracle
         # here: the base product runs on the GPU too and is compared with the report's text.
-        m, n, rp, ci, v, ncopies = blk["base"]
+        m, n, rp, ci, v, ncopies, base_report = blk["base"]
         B = sm.CsrMatrix(m, n, rp, ci, v, device=local_rank)
         d_yb = torch.empty(m, dtype=torch.float64, device="cuda")
         B.spmv(d_x[:n], d_yb, stream=stream)
         torch.cuda.synchronize()
         B.close()
         y_base = d_yb.cpu().numpy()
-        want = report_y_lines("smvp-toolbox_report_CSR_1615284663.txt")
+        want = report_y_lines(base_report)
         sc = np.add.reduceat(np.abs(v), rp[:-1])
         short = np.diff(rp) <= 32                       # summed left to right by one lane: bit-exact => same "%g" text
         text_ok = all(("%g" % y_base[i]) == want[i] for i in np.flatnonzero(short))
         num_ok = bool(np.all(np.abs(y_base - np.array([float(s) for s in want])) <= 1e-5 * sc + 1e-300))
         tiles_ok = bool(np.all(np.abs(got.reshape(ncopies, m) - y_base[None, :]) <= TOL * sc[None, :]))
         if not (text_ok and num_ok and tiles_ok):
-            raise SystemExit("rank %d: y is not tile(y_memplus of the committed report)" % rank)
-        golden = {"y_equals_tiled_reference_memplus_y": True,
+            raise SystemExit("rank %d: y is not tile(y of the committed report %s)" % (rank, base_report))
+        golden = {"y_equals_tiled_reference_memplus_y" if "1615284663" in base_report else "y_equals_tiled_reference_pwt_y": True,
                   "report_text_equal_on_rows_upto_32_entries": int(short.sum()), "rows_per_copy": int(m)}
     if gather:
         chk = float(d_y_full.sum().item())

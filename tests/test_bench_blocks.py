@@ -18,7 +18,7 @@ def args_for(**kw):
     return a
 
 
-@pytest.mark.parametrize("workload", ["memplus_tiled", "memplus_shaped", "uniform32"])
+@pytest.mark.parametrize("workload", ["memplus_tiled", "pwt_tiled", "memplus_shaped", "uniform32"])
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_blocks_tile_the_whole(workload, world):
     a = args_for()
@@ -43,7 +43,7 @@ def test_blocks_tile_the_whole(workload, world):
 def test_tiled_block_is_kron_identity_memplus():
     a = args_for(copies=3)
     blk = bench.build_block(sm, sharding, "memplus_tiled", a, 0, 1)
-    m, n, rp, ci, v, ncopies = blk["base"]
+    m, n, rp, ci, v, ncopies, report = blk["base"]
     assert ncopies == 3 and blk["rows"] == 3 * m and blk["nnz"] == 3 * len(ci)
     for c in range(3):
         a0, a1 = c * len(ci), (c + 1) * len(ci)
