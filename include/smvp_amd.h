@@ -152,14 +152,18 @@ int smvp_device_info(int device, char *name, size_t name_cap, int *compute_units
                      size_t *hbm_bytes);
 
 /* CSR kernel families (smvp_csr_set_kernel).  AUTO picks STREAM, or STREAM_CARRY when some row is
- * longer than 16384 entries. */
+ * longer than 16384 entries; it never picks COLSWEEP (whose sums are not bit-reproducible). */
 enum {
     SMVP_CSR_KERNEL_AUTO = 0,
     SMVP_CSR_KERNEL_VECTOR = 1,      /* one (sub-)wavefront per row, __shfl_down sums */
     SMVP_CSR_KERNEL_STREAM = 2,      /* fixed-nnz tiles, LDS-staged segmented reduction; a row is finished by
                                         the tile it starts in (one launch) */
-    SMVP_CSR_KERNEL_STREAM_CARRY = 3 /* same tiles; a row that crosses tiles is combined from per-tile carries
-                                        by a second small launch (for matrices with extremely long rows) */
+    SMVP_CSR_KERNEL_STREAM_CARRY = 3, /* same tiles; a row that crosses tiles is combined from per-tile carries
+                                         by a second small launch (for matrices with extremely long rows) */
+    SMVP_CSR_KERNEL_COLSWEEP = 4      /* opt-in, for columns scattered over an operand far larger than L2: row blocks
+                                         whose entries (kept a second time, sorted by column) are streamed so that all
+                                         resident workgroups gather from one L2-sized window of x; sums by LDS atomics,
+                                         so the last bits vary from run to run.  param: rows per block (1024 ... 8192) */
 };
 enum {
     SMVP_MEM_HOST = 0,  /* arrays are host memory: copied to the device */

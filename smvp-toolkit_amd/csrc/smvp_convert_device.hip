@@ -525,3 +525,93 @@ extern "C" int smvp_tjds_from_coo_device(const smvp_coo_t *d_coo, int rows, int 
         *last_diag_single = (longest > 0 && last_width == 1) ? 1 : 0;
     return SMVP_OK;
 }
+
+namespace {
+
+// row of every entry (binary search in row_ptr), packed with its column into the sort key (row block, column)
+__global__ __launch_bounds__(256) void sweep_keys(const int *__restrict__ row_ptr, const int *__restrict__ col_ind, int rows,
+                                                  int nnz, int rb_rows, u64 *__restrict__ key, unsigned *__restrict__ idx,
+                                                  unsigned short *__restrict__ local_row)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nnz)
+        return;
+    int lo = 0, hi = rows - 1;  // last row r with row_ptr[r] <= e (rows without entries share a start: take the last)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (row_ptr[mid] <= e)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    key[e] = ((u64)(unsigned)(lo / rb_rows) << 32) | (unsigned)col_ind[e];
+    idx[e] = (unsigned)e;
+    local_row[e] = (unsigned short)(lo % rb_rows);
+}
+
+__global__ __launch_bounds__(256) void sweep_gather(const u64 *__restrict__ key, const unsigned *__restrict__ idx,
+                                                    const double *__restrict__ val, const unsigned short *__restrict__ local_row,
+                                                    int nnz, int *__restrict__ e_col, double *__restrict__ e_val,
+                                                    unsigned short *__restrict__ e_row)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nnz)
+        return;
+    const unsigned e = idx[i];
+    e_col[i] = (int)(unsigned)(key[i] & 0xffffffffu);
+    e_val[i] = val[e];
+    e_row[i] = local_row[e];
+}
+
+__global__ __launch_bounds__(256) void sweep_block_bounds(const int *__restrict__ row_ptr, int rows, int rb_rows, int nrb,
+                                                          long long *__restrict__ blk_ptr)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b > nrb)
+        return;
+    const long long r = (long long)b * rb_rows;
+    blk_ptr[b] = row_ptr[r < rows ? r : rows];
+}
+
+}  // namespace
+
+namespace smvp {
+
+// Plan of the column-swept CSR kernel (csr_colsweep): the entries a second time, every block of rb_rows rows sorted by
+// column (ties in input order), with the row's number inside its block; blk_ptr[nrb + 1] = where each block starts.
+int build_colsweep_plan(const int *d_row_ptr, const int *d_col_ind, const double *d_val, int rows, int nnz, int rb_rows,
+                        long long *d_blk_ptr, int *d_e_col, double *d_e_val, unsigned short *d_e_row, hipStream_t st)
+{
+    if (rb_rows < 1 || rb_rows > 65536)
+        return smvp::fail(SMVP_ERR_INVALID, "build_colsweep_plan: bad row block height");
+    const int nrb = (rows + rb_rows - 1) / rb_rows;
+    hipLaunchKernelGGL(sweep_block_bounds, dim3(blocks_for((long long)nrb + 1)), dim3(256), 0, st, d_row_ptr, rows, rb_rows, nrb,
+                       d_blk_ptr);
+    HIP_TRY(hipGetLastError());
+    if (nnz > 0) {
+        Scratch sc;
+        u64 *k0, *k1;
+        unsigned *i0, *i1;
+        unsigned short *lr;
+        HIP_TRY(sc.get(&k0, (size_t)nnz));
+        HIP_TRY(sc.get(&k1, (size_t)nnz));
+        HIP_TRY(sc.get(&i0, (size_t)nnz));
+        HIP_TRY(sc.get(&i1, (size_t)nnz));
+        HIP_TRY(sc.get(&lr, (size_t)nnz));
+        hipLaunchKernelGGL(sweep_keys, dim3(blocks_for(nnz)), dim3(256), 0, st, d_row_ptr, d_col_ind, rows, nnz, rb_rows, k0, i0, lr);
+        HIP_TRY(hipGetLastError());
+        const unsigned bits = 32u + (unsigned)bits_for(nrb + 1);
+        size_t tmp_bytes = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, i0, i1, (size_t)nnz, 0u, bits, st));
+        char *tmp;
+        HIP_TRY(sc.get(&tmp, tmp_bytes));
+        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, i0, i1, (size_t)nnz, 0u, bits, st));
+        hipLaunchKernelGGL(sweep_gather, dim3(blocks_for(nnz)), dim3(256), 0, st, k1, i1, d_val, lr, nnz, d_e_col, d_e_val, d_e_row);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return SMVP_OK;
+}
+
+}  // namespace smvp

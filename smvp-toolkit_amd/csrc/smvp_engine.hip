@@ -131,9 +131,67 @@ struct smvp_csr {
     int *d_tile_next = nullptr;   // STREAM: row_ptr[first row of the next tile]
     int *d_carry_row = nullptr;   // STREAM_CARRY
     double *d_carry = nullptr;    // STREAM_CARRY
+    // COLSWEEP: the entries a second time, every block of sweep_rb rows sorted by column (built on the device)
+    int sweep_rb = 0, sweep_per_launch = 0;
+    long long *d_sweep_ptr = nullptr;
+    int *d_sweep_col = nullptr;
+    double *d_sweep_val = nullptr;
+    unsigned short *d_sweep_row = nullptr;
 };
 
 namespace {
+
+void free_sweep_plan(smvp_csr *h)
+{
+    for (void *p : {(void *)h->d_sweep_ptr, (void *)h->d_sweep_col, (void *)h->d_sweep_val, (void *)h->d_sweep_row})
+        if (p)
+            (void)hipFree(p);
+    h->d_sweep_ptr = nullptr;
+    h->d_sweep_col = nullptr;
+    h->d_sweep_val = nullptr;
+    h->d_sweep_row = nullptr;
+}
+
+// Row block height of the column sweep and how many row blocks start together.  A block of rb rows streams
+// rb * (mean row length) entries in column order, 1024 per pass of its workgroup, so its window moves
+// 1024 * cols / (rb * mean) columns of x per pass: the taller the block, the slower the window and the better the
+// XCD's L2 holds what the resident workgroups gather -- but the launch should still have a few hundred workgroups.
+// So: the tallest of 8192 / 4096 / 2048 / 1024 rows (8192 rows = 64 KB of sums in LDS) that leaves >= 256 row blocks,
+// but never so short that a pass moves the window by more than ~1.3 MB.  All blocks start together when they are
+// resident at once, else in even generations of at most 256.  Measured on BASELINE config 4
+// (profiles/r02_colsweep_measured.txt): 10 M rows -> 8192 / 5 x 245: 2.40 ms (4096: 2.68); one rank's eighth,
+// 1.25 M rows -> 4096 / all 305: 0.413 ms (8192: 0.478, 2048: 0.490); a 312 K-row chunk -> 2048: 0.113 ms (1024: 0.144).
+void choose_sweep_shape(int rows, int cols, int nnz, int want_rb, int *rb, int *per_launch)
+{
+    int r = 8192;
+    while (r > 1024 && (rows + r - 1) / r < 256)
+        r >>= 1;
+    const double mean = rows > 0 ? std::max(1.0, (double)nnz / rows) : 1.0;
+    int floor_rb = 1024;
+    while (floor_rb < 8192 && (double)floor_rb * mean * 160.0 < (double)cols)
+        floor_rb <<= 1;
+    r = std::max(r, floor_rb);
+    if (want_rb > 0)
+        r = want_rb;
+    const int nrb = (rows + r - 1) / r;
+    *rb = r;
+    *per_launch = nrb <= 640 ? nrb : (nrb + ((nrb + 255) / 256) - 1) / ((nrb + 255) / 256);
+}
+
+int build_sweep_plan(smvp_csr *h, int want_rb)
+{
+    free_sweep_plan(h);
+    choose_sweep_shape(h->rows, h->cols, h->nnz, want_rb, &h->sweep_rb, &h->sweep_per_launch);
+    const int nrb = (h->rows + h->sweep_rb - 1) / h->sweep_rb;
+    const size_t n = (size_t)std::max(h->nnz, 4);
+    if (hipMalloc((void **)&h->d_sweep_ptr, ((size_t)nrb + 2) * sizeof(long long)) != hipSuccess ||
+        hipMalloc((void **)&h->d_sweep_col, n * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&h->d_sweep_val, n * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&h->d_sweep_row, n * sizeof(unsigned short)) != hipSuccess)
+        return smvp::fail(SMVP_ERR_ALLOC, "cannot allocate the column-sweep plan (%d entries)", h->nnz);
+    return smvp::build_colsweep_plan(h->d_row_ptr, h->d_col_ind, h->d_val, h->rows, h->nnz, h->sweep_rb, h->d_sweep_ptr,
+                                     h->d_sweep_col, h->d_sweep_val, h->d_sweep_row, nullptr);
+}
 
 void free_stream_plan(smvp_csr *h)
 {
@@ -242,7 +300,11 @@ bool choose_csr_kernel(smvp_csr *h, int kernel, int param)
         return false;
     if (kernel == SMVP_CSR_KERNEL_STREAM_CARRY && param != 0 && param != 1024 && param != 2048)
         return false;
+    if (kernel == SMVP_CSR_KERNEL_COLSWEEP && param != 0 && param != 1024 && param != 2048 && param != 4096 && param != 8192)
+        return false;
     h->kernel = kernel;
+    if (kernel == SMVP_CSR_KERNEL_COLSWEEP)
+        return true;
     if (kernel == SMVP_CSR_KERNEL_VECTOR) {
         h->lanes_per_row = param > 0 ? param : pow2_at_least(mean);
     } else {
@@ -354,7 +416,7 @@ extern "C" int smvp_csr_set_kernel(smvp_csr_t *h, int kernel, int param)
         return smvp::fail(SMVP_ERR_INVALID, "null handle");
     if (h->flavor != smvp::kFlavorCsr && kernel != SMVP_CSR_KERNEL_STREAM)
         return smvp::fail(SMVP_ERR_UNSUPPORTED, "this matrix flavour runs on the stream kernel only");
-    if (kernel < SMVP_CSR_KERNEL_AUTO || kernel > SMVP_CSR_KERNEL_STREAM_CARRY)
+    if (kernel < SMVP_CSR_KERNEL_AUTO || kernel > SMVP_CSR_KERNEL_COLSWEEP)
         return smvp::fail(SMVP_ERR_INVALID, "unknown CSR kernel %d", kernel);
     if (kernel == SMVP_CSR_KERNEL_VECTOR && param != 0 &&
         (param < 2 || param > 64 || (param & (param - 1)) != 0))
@@ -362,7 +424,12 @@ extern "C" int smvp_csr_set_kernel(smvp_csr_t *h, int kernel, int param)
     DeviceScope on(h->device);
     if (!choose_csr_kernel(h, kernel, param))
         return smvp::fail(SMVP_ERR_INVALID, "entries per tile must be 256 (stream only), 1024 or 2048 for the kernel "
-                                            "this matrix resolves to");
+                                            "this matrix resolves to (column sweep: 1024 ... 8192 rows per block)");
+    free_sweep_plan(h);
+    if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP) {
+        free_stream_plan(h);
+        return build_sweep_plan(h, param);
+    }
     if (h->kernel != SMVP_CSR_KERNEL_VECTOR)
         return build_stream_plan(h);
     free_stream_plan(h);
@@ -376,7 +443,8 @@ extern "C" int smvp_csr_get_kernel(const smvp_csr_t *h, int *kernel, int *param)
     if (kernel)
         *kernel = h->kernel;
     if (param)
-        *param = h->kernel == SMVP_CSR_KERNEL_VECTOR ? h->lanes_per_row : h->vpt * smvp::kStreamBlock;
+        *param = h->kernel == SMVP_CSR_KERNEL_VECTOR ? h->lanes_per_row
+                 : h->kernel == SMVP_CSR_KERNEL_COLSWEEP ? h->sweep_rb : h->vpt * smvp::kStreamBlock;
     return SMVP_OK;
 }
 
@@ -385,12 +453,16 @@ static int csr_spmv_impl(smvp_csr_t *h, const double *d_x, double *d_y, void *st
 {
     if (!h || (h->rows > 0 && !d_y) || (h->nnz > 0 && !d_x))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_spmv: bad argument");
-    if (h->kernel != SMVP_CSR_KERNEL_VECTOR && !h->d_tile_row)
+    if ((h->kernel == SMVP_CSR_KERNEL_COLSWEEP && !h->d_sweep_ptr) ||
+        (h->kernel != SMVP_CSR_KERNEL_VECTOR && h->kernel != SMVP_CSR_KERNEL_COLSWEEP && !h->d_tile_row))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_spmv: the handle has no launch plan (a re-plan failed earlier)");
     DeviceScope on(h->device);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
-    if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
+    if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP)
+        e = smvp::launch_csr_colsweep(h->d_sweep_ptr, h->d_sweep_col, h->d_sweep_val, h->d_sweep_row, d_x, d_y, h->rows,
+                                      h->sweep_rb, h->sweep_per_launch, st);
+    else if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
         e = smvp::launch_csr_vector(h->lanes_per_row, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y, h->rows, st);
     else if (h->kernel == SMVP_CSR_KERNEL_STREAM) {
         smvp::OwnerLaunch l;
@@ -425,7 +497,9 @@ extern "C" int smvp_csr_describe(const smvp_csr_t *h, char *kernel_name, size_t 
     if (!h)
         return smvp::fail(SMVP_ERR_INVALID, "null handle");
     if (kernel_name && cap) {
-        if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
+        if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP)
+            snprintf(kernel_name, cap, "csr_colsweep");
+        else if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
             snprintf(kernel_name, cap, "csr_vector_rows<%d>", h->lanes_per_row);
         else if (h->kernel == SMVP_CSR_KERNEL_STREAM)
             snprintf(kernel_name, cap, "csr_stream_owner<%d, %d, false>", h->vpt, h->flavor);
@@ -443,6 +517,7 @@ extern "C" void smvp_csr_destroy(smvp_csr_t *h)
         return;
     DeviceScope on(h->device);
     free_stream_plan(h);
+    free_sweep_plan(h);
     if (h->own_row_ptr && h->d_row_ptr)
         (void)hipFree(h->d_row_ptr);
     if (h->own_col_ind && h->d_col_ind)

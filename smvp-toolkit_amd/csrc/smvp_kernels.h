@@ -10,6 +10,7 @@ constexpr int kLongRow = 32;        // segments longer than this are summed by a
 constexpr int kStreamOver = 1024;    // entries past its end a tile may finish its last row with, through LDS
 constexpr int kStreamTileGroup = 64;  // consecutive tiles per XCD turn (see tile_of_block)
 constexpr int kTjdsTileGroup = 16;    // ... for the tile-ordered TJDS stream
+constexpr int kSweepBlock = 256;   // threads per block, csr_colsweep
 constexpr int kTjdsBlock = 256;     // permuted columns per work item
 constexpr int kTjdsDiagChunk = 8;   // jagged diagonals per work item
 
@@ -49,5 +50,8 @@ hipError_t launch_tjds_permute(const int *perm, const double *x, double *x_perm,
 hipError_t launch_find_out_of_range(const int *a, long long n, int limit, int *bad, hipStream_t stream);
 hipError_t launch_normalize_max(double *v, long long n, unsigned long long *scratch, hipStream_t stream);
 hipError_t launch_fill(double *p, double v, long long n, hipStream_t stream);
+
+hipError_t launch_csr_colsweep(const long long *blk_ptr, const int *e_col, const double *e_val, const unsigned short *e_row,
+                               const double *x, double *y, int rows, int rb_rows, int per_launch, hipStream_t stream);
 
 }  // namespace smvp

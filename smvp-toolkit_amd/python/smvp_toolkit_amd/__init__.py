@@ -19,7 +19,7 @@ CLI_PATH = os.path.join(PKG_ROOT, "bin", "smvp-toolkit-cli")
 OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_IO, ERR_UNSUPPORTED = 1, 2, 3, 4, 5, 6
 MM_COULD_NOT_READ_FILE, MM_PREMATURE_EOF, MM_NOT_MTX, MM_NO_HEADER, MM_UNSUPPORTED_TYPE = 11, 12, 13, 14, 15
-CSR_KERNEL_AUTO, CSR_KERNEL_VECTOR, CSR_KERNEL_STREAM, CSR_KERNEL_STREAM_CARRY = 0, 1, 2, 3
+CSR_KERNEL_AUTO, CSR_KERNEL_VECTOR, CSR_KERNEL_STREAM, CSR_KERNEL_STREAM_CARRY, CSR_KERNEL_COLSWEEP = 0, 1, 2, 3, 4
 MEM_HOST, MEM_DEVICE = 0, 1
 SYNTH_MEMPLUS_SHAPED, SYNTH_UNIFORM = 1, 2
 TJDS_MODE_AUTO, TJDS_MODE_ATOMIC, TJDS_MODE_TWO_PHASE, TJDS_MODE_ROW_GATHER = 0, 1, 2, 3

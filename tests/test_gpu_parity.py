@@ -28,7 +28,8 @@ EXACT = {"ibm32.mtx", "curtis54.mtx", "pwt.mtx", "pdp08-pg4.mtx"}
 
 CSR_VARIANTS = [(sm.CSR_KERNEL_STREAM, 256), (sm.CSR_KERNEL_STREAM, 1024), (sm.CSR_KERNEL_STREAM, 2048),
                 (sm.CSR_KERNEL_STREAM_CARRY, 1024), (sm.CSR_KERNEL_STREAM_CARRY, 2048)] + \
-               [(sm.CSR_KERNEL_VECTOR, t) for t in (2, 4, 8, 16, 32, 64)]
+               [(sm.CSR_KERNEL_VECTOR, t) for t in (2, 4, 8, 16, 32, 64)] + \
+               [(sm.CSR_KERNEL_COLSWEEP, rb) for rb in (0, 1024, 8192)]
 
 
 @pytest.fixture(scope="module")
@@ -135,6 +136,45 @@ def test_stream_kernel_is_bitwise_serial_on_short_rows(torch):
         one_tile = short & (row_ptr[:-1] // tile == (np.maximum(row_ptr[1:], 1) - 1) // tile)
         assert one_tile.mean() > 0.9
         assert np.array_equal(y[one_tile], ref[one_tile])
+
+
+def test_colsweep_on_scattered_columns(torch):
+    """The opt-in column-swept kernel on a config-4-shaped matrix (uniform columns over an operand larger than L2):
+    same product as the tile kernel within the bound (its LDS atomics add in no fixed order), row-block heights and
+    generations as planned, AUTO never picks it."""
+    rows, cols = 700_000, 3_000_000
+    row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_UNIFORM, 2024, cols, cols, 32, 0, rows)
+    x = np.random.default_rng(9).random(cols)
+    A = sm.CsrMatrix(rows, cols, row_ptr, col_ind, val)
+    assert A.get_kernel()[0] == sm.CSR_KERNEL_STREAM
+    dx = dev(torch, x)
+    dy = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+    A.spmv(dx, dy)
+    torch.cuda.synchronize()
+    y_tile = dy.cpu().numpy()
+    scale = row_scale(row_ptr, col_ind, val, x)
+    assert_close(y_tile, ob.csr_spmv(row_ptr, col_ind, val, x), scale)
+    for rb, want in ((0, 2048), (8192, 8192), (4096, 4096)):      # 700 K rows: 2048 leaves >= 256 blocks (342)
+        A.set_kernel(sm.CSR_KERNEL_COLSWEEP, rb)
+        assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, want) and A.describe()[0] == "csr_colsweep"
+        dy.fill_(float("nan"))
+        A.spmv(dx, dy)
+        torch.cuda.synchronize()
+        assert_close(dy.cpu().numpy(), y_tile, scale)
+    with pytest.raises(sm.SmvpError):
+        A.set_kernel(sm.CSR_KERNEL_COLSWEEP, 3000)
+    A.set_kernel(sm.CSR_KERNEL_AUTO, 0)                       # back to the tile kernel, plan rebuilt
+    dy.fill_(float("nan"))
+    A.spmv(dx, dy)
+    torch.cuda.synchronize()
+    assert np.array_equal(dy.cpu().numpy(), y_tile)
+    A.close()
+    # through the reference-shaped entry point too
+    coo = sm.make_coo(np.repeat(np.arange(2000), 32), col_ind[:64000] % 2000, val[:64000])
+    y1, _, _ = sm.csr_compute(coo, 2000, 2000, iters=3, kernel=sm.CSR_KERNEL_COLSWEEP)
+    y0, _, _ = sm.csr_compute(coo, 2000, 2000, iters=3)
+    rp0, ci0, v0 = sm.csr_from_coo(coo, 2000)
+    assert_close(y1, y0, row_scale(rp0, ci0, v0, np.ones(2000)))
 
 
 def test_auto_plan_choice(torch):
