@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--rows", type=int, default=10_000_000, help="uniform32: total rows (BASELINE config 4)")
     ap.add_argument("--format", default="csr", choices=["csr", "tjds"],
                     help="storage format of the timed product (the other one is reported in extra at N = 1)")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "vector", "stream-carry"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "vector", "stream-carry", "colsweep"])
     ap.add_argument("--kernel-param", type=int, default=0)
     ap.add_argument("--x", default="ones", choices=["ones", "random"])
     ap.add_argument("--no-tjds", action="store_true", help="skip the TJDS leg (extra.tjds)")
@@ -198,7 +198,7 @@ def measure_csr(torch, dist, sm, sharding_mod, blk, args, world, local_rank, ran
         d_val = torch.from_numpy(blk["val"]).cuda()
         A = sm.CsrMatrix(blk["rows"], blk["cols_total"], d_row_ptr, d_col_ind, d_val, device=local_rank)
         if args.kernel != "auto" or args.kernel_param:
-            A.set_kernel({"auto": 0, "vector": 1, "stream": 2, "stream-carry": 3}[args.kernel], args.kernel_param)
+            A.set_kernel({"auto": 0, "vector": 1, "stream": 2, "stream-carry": 3, "colsweep": 4}[args.kernel], args.kernel_param)
     else:   # TJDS of this rank's row block, built on the GPU from the block's entries
         coo = np.zeros(blk["nnz"], dtype=sm.COO_DTYPE)
         coo["row"] = np.repeat(np.arange(blk["rows"], dtype=np.int32), np.diff(blk["row_ptr"]))
