@@ -199,24 +199,30 @@ int smvp_tjds_create(smvp_tjds_t **out, int device, int rows, int cols, int nnz,
  * kept inside the handle.  Call again whenever x changes. */
 int smvp_tjds_set_x(smvp_tjds_t *h, const double *d_x, void *stream);
 /* The timed product, main-cli.c:1013-1020, in its corrected form
- * y[row_ind[j]] += val[j] * x_perm[j - start_pos[d]].  In the default two-phase mode d_y is
+ * y[row_ind[j]] += val[j] * x_perm[j - start_pos[d]].  In the default mode (ROW_GATHER) and in TWO_PHASE d_y is
  * overwritten; in ATOMIC mode (and ref-quirks mode) d_y must be zero on entry -- the reference
  * zeroes it outside its timed window, main-cli.c:1008 -- and smvp_tjds_zero_y does that on the
  * same stream (it is a no-op when the mode does not need it, so it is always safe to call). */
 int smvp_tjds_zero_y(smvp_tjds_t *h, double *d_y, void *stream);
 int smvp_tjds_spmv(smvp_tjds_t *h, double *d_y, void *stream);
-/* How the scatter is carried out.  TWO_PHASE (default): products stored once per entry, then summed per row
- * through a row-inverted index built at create time -- no atomics, bit-reproducible, y needs no zeroing
- * (smvp_tjds_zero_y becomes a no-op).  ATOMIC: one pass, fp64 atomic adds into a zeroed y (order varies from
- * run to run).  Ref-quirks mode always runs the atomic form. */
+/* How the scatter is carried out.
+ * ROW_GATHER (default): ONE kernel per product.  At create time the entries are regrouped by row (val / row_ind /
+ *   start_pos / perm are only read); every tile of 2048 entries lists its entries in TJDS order and walks its piece of
+ *   the jagged diagonals the way the format stores them, the products meet in LDS and one lane (or wave) per row sums
+ *   them in ascending TJDS position -- no atomics, bit-reproducible, y needs no zeroing.
+ * TWO_PHASE: products stored once per entry (column-major kernel), then summed per row through a row-inverted index
+ *   -- same order of summation, same bits, two launches and 12 B per entry more traffic.
+ * ATOMIC: one column-major pass, fp64 atomic adds into a zeroed y (order varies from run to run).  Ref-quirks mode
+ *   always runs this form.
+ * The plans of the first two are built on the device the first time the mode is selected. */
 enum {
     SMVP_TJDS_MODE_AUTO = 0,               /* = ROW_GATHER */
     SMVP_TJDS_MODE_ATOMIC = 1,
     SMVP_TJDS_MODE_TWO_PHASE = 2,
-    SMVP_TJDS_MODE_ROW_GATHER = 3 /* one kernel, no atomics: the entries regrouped by row at create time */
+    SMVP_TJDS_MODE_ROW_GATHER = 3
 };
 int smvp_tjds_set_mode(smvp_tjds_t *h, int mode);
-int smvp_tjds_set_tile(smvp_tjds_t *h, int entries_per_tile); /* ROW_GATHER*: 256, 1024 or 2048 entries per workgroup */
+int smvp_tjds_set_tile(smvp_tjds_t *h, int entries_per_tile); /* ROW_GATHER: 256, 1024 or 2048 entries per workgroup (re-plans) */
 /* Reference-defect emulation for parity with the committed TJDS reports
  * (diagonal count from original column 0, missing terminator, operand indexed
  * by row: main-cli.c:865,951-966,1018).  A host-side edit of the launch plan of the atomic kernel. */
