@@ -251,6 +251,7 @@ int smvp_tjds_sharded_create(smvp_sharded_t **out, int ngpus, const int *devices
                              int rows, int cols, int nnz); /* an independent TJDS per row chunk */
 int smvp_tjds_sharded_create_ex(smvp_sharded_t **out, int ngpus, const int *devices, const smvp_coo_t *coo,
                                 int rows, int cols, int nnz, const smvp_shard_opts_t *opts);
+int smvp_sharded_set_csr_kernel(smvp_sharded_t *h, int kernel, int param); /* smvp_csr_set_kernel on every chunk */
 int smvp_sharded_set_x(smvp_sharded_t *h, const double *x_host); /* NULL = ones; replicated to every GPU */
 /* One product, asynchronous: the chunk products on every GPU and, by `allgather`, the exchange of y:
  * 0 none; SMVP_GATHER_OVERLAPPED: chunk c is gathered (communication stream) while chunk c+1 is multiplied;

@@ -1206,6 +1206,8 @@ static int sharded_compute(bool tjds, const smvp_coo_t *coo, int rows, int cols,
         local.resize((size_t)iters);
         time_each_ms = local.data();
     }
+    if (rc == SMVP_OK && !tjds && (o->csr_kernel != SMVP_CSR_KERNEL_AUTO || o->csr_param != 0))
+        rc = smvp_sharded_set_csr_kernel(h, o->csr_kernel, o->csr_param);
     if (rc == SMVP_OK)
         rc = smvp_sharded_set_x(h, o->x);
     for (int i = 0; rc == SMVP_OK && i < iters; ++i) {

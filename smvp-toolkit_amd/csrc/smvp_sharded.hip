@@ -423,6 +423,17 @@ int set_operand_everywhere(smvp_sharded *h, size_t g)
 
 }  // namespace
 
+// CSR blocks: the kernel family of every chunk handle (smvp_csr_set_kernel on each)
+extern "C" int smvp_sharded_set_csr_kernel(smvp_sharded_t *h, int kernel, int param)
+{
+    if (!h || h->format != 0)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_sharded_set_csr_kernel: not a CSR handle");
+    for (smvp_csr_t *c : h->csr)
+        if (int rc = smvp_csr_set_kernel(c, kernel, param))
+            return rc;
+    return SMVP_OK;
+}
+
 extern "C" int smvp_sharded_set_x(smvp_sharded_t *h, const double *x_host)
 {
     if (!h)

@@ -72,7 +72,7 @@ EXPORTS = [
     "smvp_tjds_create", "smvp_tjds_set_x", "smvp_tjds_zero_y", "smvp_tjds_spmv",
     "smvp_tjds_set_ref_quirks", "smvp_tjds_set_mode", "smvp_tjds_set_tile", "smvp_tjds_describe", "smvp_tjds_destroy",
     "smvp_shard_opts_default", "smvp_csr_sharded_create", "smvp_csr_sharded_create_ex", "smvp_tjds_sharded_create",
-    "smvp_tjds_sharded_create_ex", "smvp_sharded_layout", "smvp_sharded_set_x", "smvp_sharded_spmv",
+    "smvp_tjds_sharded_create_ex", "smvp_sharded_layout", "smvp_sharded_set_csr_kernel", "smvp_sharded_set_x", "smvp_sharded_spmv",
     "smvp_sharded_synchronize", "smvp_sharded_feed_back", "smvp_sharded_get_y", "smvp_sharded_info", "smvp_sharded_destroy",
     "smvp_run_opts_default", "smvp_csr_compute", "smvp_tjds_compute", "smvp_last_run_info",
     "smvp_time_stats", "smvp_generate_report_text", "smvp_cisr_coegen", "smvp_cisr_coegen_path",
@@ -118,6 +118,7 @@ def lib():
         L.smvp_shard_opts_default.argtypes = [C.POINTER(ShardOpts)]
         L.smvp_shard_opts_default.restype = None
         L.smvp_sharded_layout.argtypes = [vp, C.POINTER(ci), vp, vp]
+        L.smvp_sharded_set_csr_kernel.argtypes = [vp, ci, ci]
         L.smvp_sharded_set_x.argtypes = [vp, vp]
         L.smvp_sharded_spmv.argtypes = [vp, ci, ci]
         L.smvp_sharded_synchronize.argtypes = [vp, C.POINTER(C.c_double)]
@@ -509,6 +510,9 @@ class ShardedMatrix:
         cb = np.zeros(n * (c.value + 1), dtype=np.int32)
         _check(lib().smvp_sharded_layout(self._h, C.byref(c), _p(bounds), _p(cb)), "smvp_sharded_layout")
         return c.value, bounds, cb.reshape(n, c.value + 1)
+
+    def set_csr_kernel(self, kernel, param=0):
+        _check(lib().smvp_sharded_set_csr_kernel(self._h, kernel, param), "smvp_sharded_set_csr_kernel")
 
     def set_x(self, x=None):
         keep = None if x is None else _arr(x, np.float64)

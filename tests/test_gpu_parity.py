@@ -812,6 +812,14 @@ def test_sharded_chunks_and_both_exchange_forms(torch, chunks, balance, gather):
             assert S.synchronize() > 0
         assert_close(S.get_y(0, gathered=True), ref, scale)
         assert_close(S.get_y(0, gathered=False), ref, scale)
+        if fmt == "csr":                                   # another kernel family on every chunk
+            S.set_csr_kernel(sm.CSR_KERNEL_COLSWEEP, 1024)
+            S.spmv(allgather=gather)
+            S.synchronize()
+            assert_close(S.get_y(0, gathered=True), ref, scale)
+        else:
+            with pytest.raises(sm.SmvpError):
+                S.set_csr_kernel(sm.CSR_KERNEL_STREAM, 1024)
         S.close()
 
 
