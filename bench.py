@@ -297,7 +297,7 @@ def measure_config4(torch, dist, sm, sharding_mod, args, world, local_rank, rank
     asynchronously behind its product (chunk c travels while chunk c+1 is multiplied).
     """
     rows = args.rows
-    chunks = max(1, args.chunks) if world > 1 else 1
+    chunks = max(1, args.chunks) if (world > 1 or dist.is_initialized()) else 1   # SMVP_FORCE_DIST rehearses the chunked path with one rank
     t0 = time.perf_counter()
     ex = sharding_mod.ChunkedExchange(torch, dist, rows, world, rank, chunks, "cuda")
     threads = max(1, min(64, (os.cpu_count() or 8) // max(1, world)))
