@@ -117,12 +117,12 @@ struct smvp_csr {
     // two-phase TJDS product), or a TJDS matrix regrouped by rows (the one-kernel TJDS product); the TJDS flavours
     // borrow these arrays from their smvp_tjds owner
     int flavor = smvp::kFlavorCsr;
-    const int *d_pos = nullptr;       // TjdsK/D: what the kernel reads; TjdsS: the row-major stream the tiles are sorted from
+    const int *d_pos = nullptr;       // TjdsK: what the kernel reads; TjdsS: the row-major stream the tiles are sorted from
     const int *d_start_pos = nullptr;
     int num_diag = 0;
     // TjdsS: per-tile TJDS-ordered streams and the tiles' overflow entries, owned, rebuilt with the tile plan
     int *d_pos_sorted = nullptr, *d_meta = nullptr, *d_ovf_ptr = nullptr, *d_ovf_pos = nullptr, *d_ovf_k = nullptr;
-    int kernel = SMVP_CSR_KERNEL_AUTO;  // resolved: VECTOR or STREAM
+    int kernel = SMVP_CSR_KERNEL_AUTO;  // resolved: never AUTO once a plan exists
     int lanes_per_row = 64;             // VECTOR
     int vpt = 4;                        // STREAM: entries per thread (tile = 256 * vpt)
     int ntiles = 0;
