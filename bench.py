@@ -498,7 +498,7 @@ def live_traffic(args):
         out = tempfile.mkdtemp(prefix="smvp_pmc_", dir="/tmp")
         try:
             p = subprocess.run([rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--"] + inner,
-                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
             lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
             if p.returncode != 0 or not lines:
                 return None
