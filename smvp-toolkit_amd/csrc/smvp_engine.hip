@@ -311,8 +311,9 @@ bool choose_csr_kernel(smvp_csr *h, int kernel, int param)
         int tile = param > 0 ? param : 0;
         if (tile == 0) {  // 1024 measured 1-4 % ahead of 2048 on memplus x944 and pwt x459; 256-entry tiles when
             tile = (kernel == SMVP_CSR_KERNEL_STREAM && h->nnz < 512 * 1024) ? 256 : 1024;  // 1024 would leave CUs idle
-            if (h->flavor == smvp::kFlavorTjdsS && tile == 1024)
-                tile = 2048;  // more entries per val line inside a tile: 0.592 vs 0.62 ms on memplus x944
+            if (h->flavor == smvp::kFlavorTjdsS && tile == 1024 && h->nnz >= 48 * 1024 * 1024)
+                tile = 2048;  // more entries per val line inside a tile: 0.553 vs 0.588 ms on memplus x944 (119 M entries);
+                              // below that 1024 wins (14 M entries: 0.0630 vs 0.0663 ms; 3.5 M: 0.0201 vs 0.0219)
         }
         h->vpt = tile / smvp::kStreamBlock;
     }
