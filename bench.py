@@ -402,6 +402,60 @@ def measure_config4(torch, dist, sm, sharding_mod, args, world, local_rank, rank
     return out
 
 
+def measure_config5(torch, dist, sm, sharding_mod, world, local_rank, rank, steps):
+    """BASELINE config 5: pwt.mtx as stored (181 313 lower-triangle entries), CSR then TJDS back to back, row blocks
+    balanced by entries over `world` GPUs, each product followed by the all-gather of y when world > 1 -> extra.config5_pwt.
+    A 2.9 MB problem: more GPUs can only add the exchange to a 2 us product; reported as it comes out."""
+    tc, m, n, coo = sm.mm_read_coo(golden_file("sample-data", "pwt.mtx"))
+    rp, ci, v = sm.csr_from_coo(coo, m)
+    bounds = sm.partition_rows(rp, world).astype(np.int64) if world > 1 else np.array([0, m], dtype=np.int64)
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    lrp, lci, lv = sharding_mod.slice_csr(rp, ci, v, r0, r1)
+    A = sm.CsrMatrix(r1 - r0, n, lrp, lci, lv, device=local_rank)
+    lcoo = sm.make_coo(np.repeat(np.arange(r1 - r0), np.diff(lrp)), lci, lv)
+    T = sm.TjdsMatrix(sm.tjds_from_coo(lcoo, r1 - r0, n), device=local_rank)
+    d_x = torch.ones(n, dtype=torch.float64, device="cuda")
+    pad = int(np.diff(bounds).max())
+    y_c = torch.zeros(pad, dtype=torch.float64, device="cuda")
+    y_t = torch.zeros(pad, dtype=torch.float64, device="cuda")
+    y_full = torch.zeros(m, dtype=torch.float64, device="cuda")
+    wire = torch.empty(world * pad, dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream()
+    T.set_x(d_x, stream=stream)
+    gather = world > 1 or dist.is_initialized()
+
+    def csr_step():
+        A.spmv(d_x, y_c, stream=stream)
+        if gather:
+            sharding_mod.allgather_y(dist, y_c[:r1 - r0], y_full, bounds, wire=wire)
+
+    def tjds_step():
+        T.spmv(y_t, stream=stream)
+        if gather:
+            sharding_mod.allgather_y(dist, y_t[:r1 - r0], y_full, bounds, wire=wire)
+
+    want = np.array([float(s) for s in report_y_lines("smvp-toolbox_report_CSR_1615284671.txt")])
+    for fn, buf in ((csr_step, y_c), (tjds_step, y_t)):
+        fn()
+        torch.cuda.synchronize()
+        if not np.array_equal(buf[:r1 - r0].cpu().numpy(), want[r0:r1]) or (gather and not np.array_equal(y_full.cpu().numpy(), want)):
+            raise SystemExit("rank %d: config 5 result differs from the reference's committed pwt report" % rank)
+    out = {"workload": "pwt.mtx as stored, CSR then TJDS back to back (BASELINE config 5)", "n_gpus": world, "rows": m, "nnz": len(coo),
+           "steps": steps, "y_equals_reference_report": True,
+           "timing": "HIP events over %d back-to-back steps (max over ranks); the per-product device-timed figures of one GPU "
+                     "are in extra.sample_matrices" % steps}
+    for key, fn in (("csr", csr_step), ("tjds", tjds_step), ("csr_then_tjds", lambda: (csr_step(), tjds_step()))):
+        for _ in range(5):
+            fn()
+        wall, ev = timed_region(torch, dist, world, steps, fn)
+        out[key + "_ms_per_step"] = round(ev / steps, 6)
+    out["exchange"] = ("all_gather_into_tensor of the y blocks after every product, blocks balanced by entries and padded"
+                       if gather else "none (one GPU)")
+    A.close()
+    T.close()
+    return out
+
+
 def measure_pwt_tiled(torch, dist, sm, sharding_mod, local_rank, rank, steps):
     """pwt.mtx replicated 459x along the diagonal (16.76 M rows, 83 M stored entries): CSR and TJDS -> extra.pwt_tiled."""
     tc, m, n, coo = sm.mm_read_coo(golden_file("sample-data", "pwt.mtx"))
@@ -758,6 +812,13 @@ def main():
         except Exception as e:
             extra["config4"] = {"error": str(e)}
         torch.cuda.empty_cache()
+    if not args.no_samples:
+        try:
+            extra["config5_pwt"] = measure_config5(torch, dist, sm, sharding, world, local_rank, rank, 200)
+        except SystemExit:
+            raise
+        except Exception as e:
+            extra["config5_pwt"] = {"error": str(e)}
     if world == 1 and not args.no_pwt_tiled:
         try:
             extra["pwt_tiled"] = measure_pwt_tiled(torch, dist, sm, sharding, local_rank, rank, max(10, args.steps // 2))

@@ -641,6 +641,8 @@ def test_bench_script_runs_small(torch):
     c4, pw = j["extra"]["config4"], j["extra"]["pwt_tiled"]
     assert "error" not in c4 and c4["n_gpus"] == 1 and c4["rows"] == 300000 and c4["nnz"] == 32 * 300000 and c4["spmv_only_ms"] > 0
     assert "error" not in pw and pw["y_equals_tiled_reference_pwt_y"] and pw["tjds"]["equals_csr_bit_for_bit"]
+    c5 = j["extra"]["config5_pwt"]
+    assert "error" not in c5 and c5["y_equals_reference_report"] and 0 < c5["csr_ms_per_step"] < c5["csr_then_tjds_ms_per_step"]
     sm_ = j["extra"]["sample_matrices"]["memplus.mtx"]
     assert sm_["csr_avg_ms"] < sm_["csr_avg_ms_event_pairs"] and sm_["csr_agrees_with_cpu"] and sm_["tjds_agrees_with_cpu"]
 
