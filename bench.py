@@ -755,7 +755,7 @@ def main():
     # and launch-bound (1.9 / 2.9 MB of traffic): no HBM roofline is claimed for these.
     if rank == 0 and world == 1 and not args.no_samples:
         samples = {}
-        for name in ("memplus.mtx", "pwt.mtx"):
+        for name in ("ibm32.mtx", "memplus.mtx", "pwt.mtx"):      # BASELINE configs 1 (on the GPU: there is no CPU path), 2/3, 5
             try:
                 tc, m, n, coo = sm.mm_read_coo(golden_file("sample-data", name))
                 y_c, ms_c, st_c = sm.csr_compute(coo, m, n, iters=1000, device=local_rank)
@@ -788,7 +788,8 @@ def main():
                              csr_rows_bit_identical=round(float((y_c == y_cpu).mean()), 4))
                 # the only numbers the reference publishes: average times in its committed reports (BASELINE.md,
                 # hardware not stated) -- output-test/smvp-toolbox_report_{CSR,TJDS}_*.txt
-                published = {"memplus.mtx": (0.387638, 0.549908), "pwt.mtx": (0.569281, 1.1823)}[name]
+                published = {"ibm32.mtx": (0.0004319, 0.0007779), "memplus.mtx": (0.387638, 0.549908),
+                             "pwt.mtx": (0.569281, 1.1823)}[name]
                 e["reference_report_csr_avg_ms"], e["reference_report_tjds_avg_ms"] = published
                 e["csr_vs_reference_report"] = round(published[0] / st_c.time_avg, 1)
                 samples[name] = e
