@@ -70,7 +70,8 @@ static void help(const char *prog)
     puts("  -s, --slots=16           Number of slots for CISR.");
     puts("  -d, --dir=./             Output folder for reports.");
     puts("      --device=0           HIP device ordinal.");
-    puts("      --gpus=1             Shard the matrix by row blocks over this many GPUs (RCCL all-gather of y).");
+    puts("      --gpus=1             Shard the matrix by row blocks over this many GPUs (RCCL all-gather of y;");
+    puts("                           so far verified on hardware with one GPU only).");
     puts("      --iterate            Power iteration: feed each result back as the next operand (x <- A x, n times).");
     puts("      --normalize          --iterate, and divide every iterate by its largest magnitude.");
     puts("      --ref-quirks         Reproduce the reference v0.6.4 TJDS output, defects included.");
