@@ -151,8 +151,10 @@ int smvp_device_count(int *count);
 int smvp_device_info(int device, char *name, size_t name_cap, int *compute_units,
                      size_t *hbm_bytes);
 
-/* CSR kernel families (smvp_csr_set_kernel).  AUTO picks STREAM, or STREAM_CARRY when some row is
- * longer than 16384 entries; it never picks COLSWEEP (whose sums are not bit-reproducible). */
+/* CSR kernel families (smvp_csr_set_kernel).  AUTO picks STREAM; STREAM_CARRY when some row is longer
+ * than 16384 entries; COLSWEEP for a large matrix whose gathers scatter over an operand much larger than
+ * the L2 (measured at create time on samples of col_ind).  Every family gives the same result from run
+ * to run. */
 enum {
     SMVP_CSR_KERNEL_AUTO = 0,
     SMVP_CSR_KERNEL_VECTOR = 1,      /* one (sub-)wavefront per row, __shfl_down sums */
@@ -160,10 +162,11 @@ enum {
                                         the tile it starts in (one launch) */
     SMVP_CSR_KERNEL_STREAM_CARRY = 3, /* same tiles; a row that crosses tiles is combined from per-tile carries
                                          by a second small launch (for matrices with extremely long rows) */
-    SMVP_CSR_KERNEL_COLSWEEP = 4      /* opt-in, for columns scattered over an operand far larger than L2: row blocks
-                                         whose entries (kept a second time, sorted by column) are streamed so that all
-                                         resident workgroups gather from one L2-sized window of x; sums by LDS atomics,
-                                         so the last bits vary from run to run.  param: rows per block (1024 ... 8192) */
+    SMVP_CSR_KERNEL_COLSWEEP = 4      /* for columns scattered over an operand far larger than L2: strips of rows whose
+                                         entries (kept a second time, sorted by column) are streamed so that all
+                                         resident wavefronts gather from one L2-sized window of x; every row is
+                                         summed in ascending column order like main-cli.c:410-416 (bit-identical to
+                                         it).  param: rows per workgroup of four strips (1024 ... 8192) */
 };
 enum {
     SMVP_MEM_HOST = 0,  /* arrays are host memory: copied to the device */
@@ -182,6 +185,10 @@ int smvp_csr_create(smvp_csr_t **out, int device, int rows, int cols, int nnz,
                     int mem_kind, const int *host_row_ptr);
 int smvp_csr_set_kernel(smvp_csr_t *h, int kernel, int param); /* param: lanes per row (VECTOR) / nnz per tile (STREAM), 0 = default */
 int smvp_csr_get_kernel(const smvp_csr_t *h, int *kernel, int *param);
+/* What AUTO's choice of COLSWEEP rests on: the share (0 ... 1) of the matrix's gathers that pull their own
+ * 128-byte line of x through the L2, estimated on 64 samples of 65536 consecutive entries of col_ind (measured
+ * on first use, then kept); -1 for matrices of fewer than 4 M entries, which are not sampled. */
+int smvp_csr_gather_spread(smvp_csr_t *h, double *spread);
 /* The timed product, main-cli.c:410-416: d_y[0..rows) = A * d_x[0..cols).  Asynchronous
  * on `stream`; d_y is fully overwritten (no pre-zeroing needed). */
 int smvp_csr_spmv(smvp_csr_t *h, const double *d_x, double *d_y, void *stream);

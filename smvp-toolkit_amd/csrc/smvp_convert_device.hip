@@ -528,9 +528,9 @@ extern "C" int smvp_tjds_from_coo_device(const smvp_coo_t *d_coo, int rows, int 
 
 namespace {
 
-// row of every entry (binary search in row_ptr), packed with its column into the sort key (row block, column)
+// row of every entry (binary search in row_ptr), packed with its column into the sort key (row strip, column)
 __global__ __launch_bounds__(256) void sweep_keys(const int *__restrict__ row_ptr, const int *__restrict__ col_ind, int rows,
-                                                  int nnz, int rb_rows, u64 *__restrict__ key, unsigned *__restrict__ idx,
+                                                  int nnz, int strip_rows, u64 *__restrict__ key, unsigned *__restrict__ idx,
                                                   unsigned short *__restrict__ local_row)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -544,15 +544,15 @@ __global__ __launch_bounds__(256) void sweep_keys(const int *__restrict__ row_pt
         else
             hi = mid - 1;
     }
-    key[e] = ((u64)(unsigned)(lo / rb_rows) << 32) | (unsigned)col_ind[e];
+    key[e] = ((u64)(unsigned)(lo / strip_rows) << 32) | (unsigned)col_ind[e];
     idx[e] = (unsigned)e;
-    local_row[e] = (unsigned short)(lo % rb_rows);
+    local_row[e] = (unsigned short)(lo % strip_rows);
 }
 
 __global__ __launch_bounds__(256) void sweep_gather(const u64 *__restrict__ key, const unsigned *__restrict__ idx,
                                                     const double *__restrict__ val, const unsigned short *__restrict__ local_row,
                                                     int nnz, int *__restrict__ e_col, double *__restrict__ e_val,
-                                                    unsigned short *__restrict__ e_row)
+                                                    unsigned short *__restrict__ row_sorted)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nnz)
@@ -560,53 +560,81 @@ __global__ __launch_bounds__(256) void sweep_gather(const u64 *__restrict__ key,
     const unsigned e = idx[i];
     e_col[i] = (int)(unsigned)(key[i] & 0xffffffffu);
     e_val[i] = val[e];
-    e_row[i] = local_row[e];
+    row_sorted[i] = local_row[e];
 }
 
-__global__ __launch_bounds__(256) void sweep_block_bounds(const int *__restrict__ row_ptr, int rows, int rb_rows, int nrb,
-                                                          long long *__restrict__ blk_ptr)
+// The product kernel takes a strip's stream `chunk` entries at a time (one wavefront, chunk / 64 entries per lane).
+// turn = how many earlier entries of the same chunk belong to the same row: entries with equal turns never share a
+// row, so the wavefront adds turn 0, then turn 1, ... and every row is summed in stream order -- ascending column,
+// the order of main-cli.c:410-416 -- whatever else is in flight.  Turns from turn_cap on are stored as turn_cap.
+__global__ __launch_bounds__(256) void sweep_turns(const u64 *__restrict__ key, const long long *__restrict__ strip_ptr,
+                                                   const unsigned short *__restrict__ row_sorted, int nnz, int chunk,
+                                                   int row_bits, int turn_cap, unsigned short *__restrict__ e_row)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nnz)
+        return;
+    const long long a = strip_ptr[(unsigned)(key[i] >> 32)];
+    const long long first = a + ((long long)i - a) / chunk * chunk;
+    const unsigned short mine = row_sorted[i];
+    int turn = 0;
+    for (long long q = first; q < i; ++q)
+        turn += row_sorted[q] == mine ? 1 : 0;
+    e_row[i] = (unsigned short)(mine | ((turn < turn_cap ? turn : turn_cap) << row_bits));
+}
+
+__global__ __launch_bounds__(256) void sweep_strip_bounds(const int *__restrict__ row_ptr, int rows, int strip_rows, int nstrips,
+                                                          long long *__restrict__ strip_ptr)
 {
     const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b > nrb)
+    if (b > nstrips)
         return;
-    const long long r = (long long)b * rb_rows;
-    blk_ptr[b] = row_ptr[r < rows ? r : rows];
+    const long long r = (long long)b * strip_rows;
+    strip_ptr[b] = row_ptr[r < rows ? r : rows];
 }
 
 }  // namespace
 
 namespace smvp {
 
-// Plan of the column-swept CSR kernel (csr_colsweep): the entries a second time, every block of rb_rows rows sorted by
-// column (ties in input order), with the row's number inside its block; blk_ptr[nrb + 1] = where each block starts.
-int build_colsweep_plan(const int *d_row_ptr, const int *d_col_ind, const double *d_val, int rows, int nnz, int rb_rows,
-                        long long *d_blk_ptr, int *d_e_col, double *d_e_val, unsigned short *d_e_row, hipStream_t st)
+// Plan of the column-swept CSR kernel (csr_colsweep): the entries a second time, every strip of strip_rows rows (one
+// wavefront's share) sorted by column (ties in input order), each with its row's number inside the strip and its turn
+// inside its chunk of `chunk` stream entries (see sweep_turns), packed as row | turn << row_bits;
+// strip_ptr[nstrips + 1] = where each strip's stream starts.
+int build_colsweep_plan(const int *d_row_ptr, const int *d_col_ind, const double *d_val, int rows, int nnz, int strip_rows,
+                        int chunk, int row_bits, int turn_cap, long long *d_strip_ptr, int *d_e_col, double *d_e_val,
+                        unsigned short *d_e_row, hipStream_t st)
 {
-    if (rb_rows < 1 || rb_rows > 65536)
-        return smvp::fail(SMVP_ERR_INVALID, "build_colsweep_plan: bad row block height");
-    const int nrb = (rows + rb_rows - 1) / rb_rows;
-    hipLaunchKernelGGL(sweep_block_bounds, dim3(blocks_for((long long)nrb + 1)), dim3(256), 0, st, d_row_ptr, rows, rb_rows, nrb,
-                       d_blk_ptr);
+    if (strip_rows < 1 || strip_rows > (1 << row_bits) || row_bits < 1 || row_bits > 15 || chunk < 64 ||
+        turn_cap != (1 << (16 - row_bits)) - 1)
+        return smvp::fail(SMVP_ERR_INVALID, "build_colsweep_plan: bad strip shape");
+    const int nstrips = (rows + strip_rows - 1) / strip_rows;
+    hipLaunchKernelGGL(sweep_strip_bounds, dim3(blocks_for((long long)nstrips + 1)), dim3(256), 0, st, d_row_ptr, rows,
+                       strip_rows, nstrips, d_strip_ptr);
     HIP_TRY(hipGetLastError());
     if (nnz > 0) {
         Scratch sc;
         u64 *k0, *k1;
         unsigned *i0, *i1;
-        unsigned short *lr;
+        unsigned short *lr, *lr_sorted;
         HIP_TRY(sc.get(&k0, (size_t)nnz));
         HIP_TRY(sc.get(&k1, (size_t)nnz));
         HIP_TRY(sc.get(&i0, (size_t)nnz));
         HIP_TRY(sc.get(&i1, (size_t)nnz));
         HIP_TRY(sc.get(&lr, (size_t)nnz));
-        hipLaunchKernelGGL(sweep_keys, dim3(blocks_for(nnz)), dim3(256), 0, st, d_row_ptr, d_col_ind, rows, nnz, rb_rows, k0, i0, lr);
+        HIP_TRY(sc.get(&lr_sorted, (size_t)nnz));
+        hipLaunchKernelGGL(sweep_keys, dim3(blocks_for(nnz)), dim3(256), 0, st, d_row_ptr, d_col_ind, rows, nnz, strip_rows, k0, i0, lr);
         HIP_TRY(hipGetLastError());
-        const unsigned bits = 32u + (unsigned)bits_for(nrb + 1);
+        const unsigned bits = 32u + (unsigned)bits_for(nstrips + 1);
         size_t tmp_bytes = 0;
         HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, i0, i1, (size_t)nnz, 0u, bits, st));
         char *tmp;
         HIP_TRY(sc.get(&tmp, tmp_bytes));
         HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, i0, i1, (size_t)nnz, 0u, bits, st));
-        hipLaunchKernelGGL(sweep_gather, dim3(blocks_for(nnz)), dim3(256), 0, st, k1, i1, d_val, lr, nnz, d_e_col, d_e_val, d_e_row);
+        hipLaunchKernelGGL(sweep_gather, dim3(blocks_for(nnz)), dim3(256), 0, st, k1, i1, d_val, lr, nnz, d_e_col, d_e_val, lr_sorted);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(sweep_turns, dim3(blocks_for(nnz)), dim3(256), 0, st, k1, d_strip_ptr, lr_sorted, nnz, chunk, row_bits,
+                           turn_cap, d_e_row);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));
     }

@@ -131,8 +131,10 @@ struct smvp_csr {
     int *d_tile_next = nullptr;   // STREAM: row_ptr[first row of the next tile]
     int *d_carry_row = nullptr;   // STREAM_CARRY
     double *d_carry = nullptr;    // STREAM_CARRY
-    // COLSWEEP: the entries a second time, every block of sweep_rb rows sorted by column (built on the device)
+    // COLSWEEP: the entries a second time, every strip of sweep_rb / 4 rows sorted by column (built on the device);
+    // sweep_rb = rows per workgroup (four wavefronts, one strip each)
     int sweep_rb = 0, sweep_per_launch = 0;
+    double spread = -2.0;  // share of gathers that pull their own line of x (csr_gather_spread); -2: not measured yet
     long long *d_sweep_ptr = nullptr;
     int *d_sweep_col = nullptr;
     double *d_sweep_val = nullptr;
@@ -152,8 +154,8 @@ void free_sweep_plan(smvp_csr *h)
     h->d_sweep_row = nullptr;
 }
 
-// Row block height of the column sweep and how many row blocks start together.  A block of rb rows streams
-// rb * (mean row length) entries in column order, 1024 per pass of its workgroup, so its window moves
+// Rows per workgroup of the column sweep (four strips) and how many workgroups start together.  A block of rb rows streams
+// rb * (mean row length) entries in column order, 1024 per pass of its workgroup (256 per strip), so its window moves
 // 1024 * cols / (rb * mean) columns of x per pass: the taller the block, the slower the window and the better the
 // XCD's L2 holds what the resident workgroups gather -- but the launch should still have a few hundred workgroups.
 // So: the tallest of 8192 / 4096 / 2048 / 1024 rows (8192 rows = 64 KB of sums in LDS) that leaves >= 256 row blocks,
@@ -182,15 +184,67 @@ int build_sweep_plan(smvp_csr *h, int want_rb)
 {
     free_sweep_plan(h);
     choose_sweep_shape(h->rows, h->cols, h->nnz, want_rb, &h->sweep_rb, &h->sweep_per_launch);
-    const int nrb = (h->rows + h->sweep_rb - 1) / h->sweep_rb;
+    const int strip_rows = h->sweep_rb / smvp::kSweepWaves;
+    const int nstrips = (h->rows + strip_rows - 1) / strip_rows;
     const size_t n = (size_t)std::max(h->nnz, 4);
-    if (hipMalloc((void **)&h->d_sweep_ptr, ((size_t)nrb + 2) * sizeof(long long)) != hipSuccess ||
+    if (hipMalloc((void **)&h->d_sweep_ptr, ((size_t)nstrips + 2) * sizeof(long long)) != hipSuccess ||
         hipMalloc((void **)&h->d_sweep_col, n * sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&h->d_sweep_val, n * sizeof(double)) != hipSuccess ||
         hipMalloc((void **)&h->d_sweep_row, n * sizeof(unsigned short)) != hipSuccess)
         return smvp::fail(SMVP_ERR_ALLOC, "cannot allocate the column-sweep plan (%d entries)", h->nnz);
-    return smvp::build_colsweep_plan(h->d_row_ptr, h->d_col_ind, h->d_val, h->rows, h->nnz, h->sweep_rb, h->d_sweep_ptr,
+    return smvp::build_colsweep_plan(h->d_row_ptr, h->d_col_ind, h->d_val, h->rows, h->nnz, strip_rows, smvp::kSweepChunk, smvp::kSweepRowBits, smvp::kSweepTurnCap, h->d_sweep_ptr,
                                      h->d_sweep_col, h->d_sweep_val, h->d_sweep_row, nullptr);
+}
+
+// Share of the gathers of a (large) CSR matrix that pull their own 128-byte line of x through the L2, estimated on
+// kSpreadSamples runs of 64 K consecutive entries -- one XCD's turn of the tile kernel -- by linear counting
+// (smvp_kernels.hip: csr_line_spread): distinct lines / entries, 0 ... 1.  -1: too small to sample, or the probe failed.
+constexpr int kSpreadSamples = 64;
+double csr_gather_spread(const smvp_csr *h)
+{
+    if ((long long)h->nnz < (long long)kSpreadSamples * smvp::kSpreadSpan || !h->d_col_ind)
+        return -1.0;
+    int *d_bits = nullptr;
+    if (hipMalloc((void **)&d_bits, sizeof(int) * kSpreadSamples) != hipSuccess)
+        return -1.0;
+    int bits[kSpreadSamples];
+    hipError_t e = smvp::launch_csr_line_spread(h->d_col_ind, h->nnz, kSpreadSamples, d_bits, nullptr);
+    if (e == hipSuccess)
+        e = hipMemcpy(bits, d_bits, sizeof bits, hipMemcpyDeviceToHost);
+    (void)hipFree(d_bits);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return -1.0;
+    }
+    const double m = 512.0 * 1024.0;  // bits in the map
+    double lines = 0.0;
+    for (int b : bits)
+        lines += -m * std::log(std::max(1.0 - b / m, 1.0 / m));  // linear counting: n = -m ln(share of clear bits)
+    return std::min(1.0, lines / ((double)kSpreadSamples * smvp::kSpreadSpan));
+}
+
+// AUTO picks the column sweep when the tile kernel would be bound by L2-miss gathers and the sweep's window can hold:
+//  * the operand is at least twice an XCD's 4 MB L2 (else the tile kernel's gathers hit anyway; measured on uniform
+//    rows of 32: 8 MB operand 0.340 -> 0.205 ms, 16 MB 0.907 -> 0.403, 32 MB 2.20 -> 0.81, 80 MB 6.2 -> 2.45), rows
+//    of at least 4 entries on average;
+//  * most gathers pull their own line: spread >= kSweepMinSpread.  Tile kernel: spread * nnz / 54 G lines/s (measured:
+//    config 4, spread 0.95, 5.98 ms; the SURVEY 8(d) random model, 0.42, 1.03 ms); sweep: nnz / 133 G/s;
+//  * a workgroup's 8192 rows hold enough entries that a pass moves its window by about 1 MB at most
+//    (choose_sweep_shape) -- the random model's 7 entries per row over 16.7 M columns do not, and the sweep loses there
+//    (profiles/r02_colsweep_measured.txt);
+//  * no row is so long that its strip becomes the critical path; the matrix is worth a second copy (>= 4 M entries).
+constexpr double kSweepMinSpread = 0.6;
+bool sweep_suits(smvp_csr *h)
+{
+    if (h->flavor != smvp::kFlavorCsr || h->nnz < 4 * 1024 * 1024 || h->rows < 4096)
+        return false;
+    const double mean = (double)h->nnz / h->rows;
+    if (mean < 4.0 || (double)h->cols * 8.0 < 8.0 * 1024 * 1024 || 8192.0 * mean * 160.0 < (double)h->cols ||
+        (double)h->max_row_len > 256.0 * mean)
+        return false;
+    if (h->spread < -1.5)
+        h->spread = csr_gather_spread(h);
+    return h->spread >= kSweepMinSpread;
 }
 
 void free_stream_plan(smvp_csr *h)
@@ -295,7 +349,9 @@ bool choose_csr_kernel(smvp_csr *h, int kernel, int param)
 {
     const double mean = h->rows > 0 ? (double)h->nnz / h->rows : 0.0;
     if (kernel == SMVP_CSR_KERNEL_AUTO)
-        kernel = h->max_row_len > kOwnerMaxRow ? SMVP_CSR_KERNEL_STREAM_CARRY : SMVP_CSR_KERNEL_STREAM;
+        kernel = h->max_row_len > kOwnerMaxRow ? SMVP_CSR_KERNEL_STREAM_CARRY
+                 : sweep_suits(h)              ? SMVP_CSR_KERNEL_COLSWEEP
+                                               : SMVP_CSR_KERNEL_STREAM;
     if (kernel == SMVP_CSR_KERNEL_STREAM && param != 0 && param != 256 && param != 1024 && param != 2048)
         return false;
     if (kernel == SMVP_CSR_KERNEL_STREAM_CARRY && param != 0 && param != 1024 && param != 2048)
@@ -393,7 +449,14 @@ static int csr_create_impl(smvp_csr_t **out, int device, int rows, int cols, int
     if (rc == SMVP_OK) {
         // every flavour but plain CSR exists for the owner-completes kernel only
         choose_csr_kernel(h, plain ? SMVP_CSR_KERNEL_AUTO : SMVP_CSR_KERNEL_STREAM, 0);
-        if (h->kernel != SMVP_CSR_KERNEL_VECTOR)
+        if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP && build_sweep_plan(h, 0) != SMVP_OK) {
+            // AUTO's second copy of the entries did not fit: the tile kernel needs none
+            (void)hipGetLastError();
+            free_sweep_plan(h);
+            h->spread = -1.0;
+            choose_csr_kernel(h, SMVP_CSR_KERNEL_STREAM, 0);
+        }
+        if (h->kernel != SMVP_CSR_KERNEL_VECTOR && h->kernel != SMVP_CSR_KERNEL_COLSWEEP)
             rc = build_stream_plan(h);
     }
     if (rc != SMVP_OK) {
@@ -449,6 +512,17 @@ extern "C" int smvp_csr_get_kernel(const smvp_csr_t *h, int *kernel, int *param)
     return SMVP_OK;
 }
 
+extern "C" int smvp_csr_gather_spread(smvp_csr_t *h, double *spread)
+{
+    if (!h || !spread)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_gather_spread: bad argument");
+    DeviceScope on(h->device);
+    if (h->spread < -1.5)
+        h->spread = h->flavor == smvp::kFlavorCsr ? csr_gather_spread(h) : -1.0;
+    *spread = h->spread;
+    return SMVP_OK;
+}
+
 // stamps: device-side timing slots of this launch (owner kernel only), or nullptr
 static int csr_spmv_impl(smvp_csr_t *h, const double *d_x, double *d_y, void *stream, unsigned long long *stamps)
 {
@@ -462,7 +536,7 @@ static int csr_spmv_impl(smvp_csr_t *h, const double *d_x, double *d_y, void *st
     hipError_t e;
     if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP)
         e = smvp::launch_csr_colsweep(h->d_sweep_ptr, h->d_sweep_col, h->d_sweep_val, h->d_sweep_row, d_x, d_y, h->rows,
-                                      h->sweep_rb, h->sweep_per_launch, st);
+                                      h->sweep_rb / smvp::kSweepWaves, h->sweep_per_launch, st);
     else if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
         e = smvp::launch_csr_vector(h->lanes_per_row, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y, h->rows, st);
     else if (h->kernel == SMVP_CSR_KERNEL_STREAM) {

@@ -10,7 +10,12 @@ constexpr int kLongRow = 32;        // segments longer than this are summed by a
 constexpr int kStreamOver = 1024;    // entries past its end a tile may finish its last row with, through LDS
 constexpr int kStreamTileGroup = 64;  // consecutive tiles per XCD turn (see tile_of_block)
 constexpr int kTjdsTileGroup = 16;    // ... for the tile-ordered TJDS stream
-constexpr int kSweepBlock = 256;   // threads per block, csr_colsweep
+constexpr int kSweepBlock = 256;   // threads per block, csr_colsweep: four wavefronts, each with its own strip of rows
+constexpr int kSweepWaves = kSweepBlock / 64;
+constexpr int kSweepUnroll = 4;    // stream entries per lane and pass: a wavefront takes its strip 256 entries at a time
+constexpr int kSweepChunk = 64 * kSweepUnroll;
+constexpr int kSweepRowBits = 11;  // a strip holds at most 2048 rows (16 KB of sums in LDS) ...
+constexpr int kSweepTurnCap = (1 << (16 - kSweepRowBits)) - 1;  // ... and the 16-bit row word carries the entry's turn, capped
 constexpr int kTjdsBlock = 256;     // permuted columns per work item
 constexpr int kTjdsDiagChunk = 8;   // jagged diagonals per work item
 
@@ -51,7 +56,10 @@ hipError_t launch_find_out_of_range(const int *a, long long n, int limit, int *b
 hipError_t launch_normalize_max(double *v, long long n, unsigned long long *scratch, hipStream_t stream);
 hipError_t launch_fill(double *p, double v, long long n, hipStream_t stream);
 
-hipError_t launch_csr_colsweep(const long long *blk_ptr, const int *e_col, const double *e_val, const unsigned short *e_row,
-                               const double *x, double *y, int rows, int rb_rows, int per_launch, hipStream_t stream);
+hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, const double *e_val, const unsigned short *e_row,
+                               const double *x, double *y, int rows, int strip_rows, int per_launch, hipStream_t stream);
+// entries of 64 K-entry samples of a CSR matrix that gather from distinct 128-byte lines of x (see csr_line_spread)
+constexpr int kSpreadSpan = 64 * 1024;
+hipError_t launch_csr_line_spread(const int *col_ind, long long nnz, int samples, int *distinct, hipStream_t stream);
 
 }  // namespace smvp

@@ -928,74 +928,208 @@ hipError_t launch_fill(double *p, double v, long long n, hipStream_t stream)
 }  // namespace smvp
 
 // ---------------------------------------------------------------------------
-// K4: CSR, column-swept row blocks -- for matrices whose columns scatter over an operand far larger than L2
+// K4: CSR, column-swept row strips -- for matrices whose columns scatter over an operand far larger than L2
 // (BASELINE config 4: 32 uniform columns per row over an 80 MB x).  The tile kernels above then run at the chip's
 // L2-miss gather rate (about 54 G gathers/s, 8.4 % of HBM peak on config 4) whatever they do, because every gather
 // fetches its own line from the Infinity Cache.  Here the entries are kept a second time (the plan; row_ptr /
-// col_ind / val stay as they are), ordered by (row block, column) with a 16-bit row number inside the block.  One
-// workgroup owns a row block: it keeps the block's sums in LDS and streams its entries in ascending column order,
-// so all the workgroups that run together gather from one window of x that slides over the operand once per
-// product and fits the XCD's 4 MB L2 (measured 135 G gathers/s on config 4: 2.37 ms against 5.98).  The launches
-// are cut into generations of row blocks that are resident together and start together (per_launch), which is
-// what keeps their windows aligned; a row block's sums are complete when its generation ends.
-// The sums inside a row are added by LDS atomics as the entries come by: unlike every other kernel here the order
-// is not fixed, so results vary in the last bits from run to run (within the usual rounding bound).  Opt-in.
+// col_ind / val stay as they are), ordered by (row strip, column) with a 16-bit word per entry: the row's number inside
+// the strip and the entry's turn (below).  One WAVEFRONT owns a strip of up to 2048 rows: it keeps the strip's sums in
+// its own quarter of the workgroup's LDS and streams the strip's entries in ascending column order, 256 at a time, so
+// all the wavefronts that run together gather from one window of x that slides over the operand once per product and
+// fits the XCD's 4 MB L2 (measured 135 G gathers/s on config 4: 2.4 ms against 5.98).  The launches are cut into
+// generations of workgroups that are resident together and start together (per_launch), which is what keeps their
+// windows aligned; a strip's sums are complete when its wavefront ends.
+//
+// Every row is summed in ascending column order -- the order of the serial loop, main-cli.c:410-416 -- so the result
+// is bit-identical to it and the same from run to run.  (Round 2 added the products with LDS atomics in arrival order.)
+// A strip belongs to one wavefront, whose LDS instructions execute in program order, so only entries of one row that
+// meet in the same chunk of 256 need ordering: the plan gives each entry its turn, the number of earlier entries of
+// its row in its chunk, entries of equal turn never share a row, and the wavefront adds turn 0 (nearly everything),
+// then turn 1, ...  Turns from kSweepTurnCap on (a dense row in a narrow band of columns: not what this kernel is for,
+// but it must stay right) are added one lane at a time in stream order.  No atomics, no barriers.
 // ---------------------------------------------------------------------------
 namespace smvp {
 
+// One iteration of a wavefront takes G chunks of its strip (G * 256 entries, G * 4 per lane): all their gathers are in
+// flight together, the plan words of the next iteration are requested before the sums are touched, and the chunks are
+// then added one after the other (a chunk's turns are counted inside the chunk, so this keeps every row in order).
+template <int G>
 __global__ __launch_bounds__(kSweepBlock) void csr_colsweep(
-    const long long *__restrict__ blk_ptr, const int *__restrict__ e_col, const double *__restrict__ e_val,
-    const unsigned short *__restrict__ e_row, const double *__restrict__ x, double *__restrict__ y, int rows, int rb_rows,
-    int rb_first)
+    const long long *__restrict__ strip_ptr, const int *__restrict__ e_col, const double *__restrict__ e_val,
+    const unsigned short *__restrict__ e_row, const double *__restrict__ x, double *__restrict__ y, int rows, int strip_rows,
+    int nstrips, int wg_first)
 {
-    constexpr int UNROLL = 4;
-    extern __shared__ double acc[];
-    const int rb = rb_first + blockIdx.x, t = threadIdx.x;
-    for (int i = t; i < rb_rows; i += kSweepBlock)
-        acc[i] = 0.0;
-    __syncthreads();
-    const long long a = blk_ptr[rb], z = blk_ptr[rb + 1];
-    for (long long j = a + t; j < z; j += (long long)kSweepBlock * UNROLL) {
-        int c[UNROLL];
-        double v[UNROLL];
-        unsigned short r[UNROLL];
+    constexpr int U = kSweepUnroll, E = G * U;
+    constexpr long long STEP = (long long)G * kSweepChunk;
+    extern __shared__ double sums_all[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int strip = (wg_first + (int)blockIdx.x) * kSweepWaves + wave;
+    if (strip >= nstrips)
+        return;  // (no barrier anywhere in this kernel)
+    // volatile: every access is issued where it stands -- another lane's earlier store must be seen; the LDS address
+    // space is spelled out so that these stay ds_read / ds_write
+    typedef __attribute__((address_space(3))) volatile double lds_double;
+    lds_double *sums = (lds_double *)sums_all + (size_t)wave * strip_rows;
+    const long long a = strip_ptr[strip], z = strip_ptr[strip + 1];
+
+    // entry e of an iteration starting at `base`: stream position base + e * 64 + lane; w = row | turn << kSweepRowBits,
+    // -1 where the stream has ended
+    auto fetch = [&](long long base, int (&c)[E], double (&v)[E], int (&w)[E]) {
+        if (base + STEP <= z) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const long long jj = j + (long long)u * kSweepBlock;
-            const bool in = jj < z;
-            c[u] = in ? e_col[jj] : 0;
-            v[u] = in ? e_val[jj] : 0.0;
-            r[u] = in ? e_row[jj] : (unsigned short)0;
+            for (int e = 0; e < E; ++e) {
+                const long long j = base + e * 64 + lane;
+                c[e] = __builtin_nontemporal_load(e_col + j);
+                v[e] = __builtin_nontemporal_load(e_val + j);
+                w[e] = __builtin_nontemporal_load(e_row + j);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const long long j = base + e * 64 + lane;
+                const bool in = j < z;
+                c[e] = in ? e_col[j] : 0;
+                v[e] = in ? e_val[j] : 0.0;
+                w[e] = in ? (int)e_row[j] : -1;
+            }
         }
-        double xv[UNROLL];
+    };
+    int c[E], w[E];
+    double v[E];
+    if (a < z)
+        fetch(a, c, v, w);
+    for (int i = lane; i < strip_rows; i += 64)
+        sums[i] = 0.0;
+    for (long long base = a; base < z; base += STEP) {
+        double p[E];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-            xv[u] = x[c[u]];
+        for (int e = 0; e < E; ++e)
+            p[e] = x[c[e]];
+        int cn[E], wn[E];
+        double vn[E];
+        if (base + STEP < z)
+            fetch(base + STEP, cn, vn, wn);
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-            if (j + (long long)u * kSweepBlock < z)
-                atomicAdd(&acc[r[u]], v[u] * xv[u]);
+        for (int e = 0; e < E; ++e)
+            p[e] = v[e] * p[e];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            int row[U], turn[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                row[u] = w[g * U + u] < 0 ? 0 : w[g * U + u] & ((1 << kSweepRowBits) - 1);
+                turn[u] = w[g * U + u] >> kSweepRowBits;  // -1 stays -1: no entry
+            }
+            for (int k = 0;; ++k) {
+                double cur[U];
+                bool later = false;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    cur[u] = sums[row[u]];  // every lane reads (row 0 where it has no entry): four reads in flight, no branches
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (turn[u] == k)
+                        sums[row[u]] = cur[u] + p[g * U + u];
+                    later = later || (turn[u] > k && turn[u] < kSweepTurnCap);
+                }
+                if (!__any(later))
+                    break;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                unsigned long long m = __ballot(turn[u] == kSweepTurnCap);
+                while (m) {  // lane by lane, i.e. in stream order
+                    const int l = __ffsll((long long)m) - 1;
+                    if (lane == l)
+                        sums[row[u]] = sums[row[u]] + p[g * U + u];
+                    m &= m - 1;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            c[e] = cn[e];
+            v[e] = vn[e];
+            w[e] = wn[e];
+        }
     }
-    __syncthreads();
-    const long long r0 = (long long)rb * rb_rows;
-    for (int i = t; i < rb_rows && r0 + i < rows; i += kSweepBlock)
-        y[r0 + i] = acc[i];
+    const long long r0 = (long long)strip * strip_rows;
+    for (int i = lane; i < strip_rows && r0 + i < rows; i += 64)
+        __builtin_nontemporal_store(sums[i], &y[r0 + i]);
 }
 
-hipError_t launch_csr_colsweep(const long long *blk_ptr, const int *e_col, const double *e_val, const unsigned short *e_row,
-                               const double *x, double *y, int rows, int rb_rows, int per_launch, hipStream_t stream)
+hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, const double *e_val, const unsigned short *e_row,
+                               const double *x, double *y, int rows, int strip_rows, int per_launch, hipStream_t stream)
 {
     if (rows <= 0)
         return hipSuccess;
-    const int nrb = (rows + rb_rows - 1) / rb_rows;
-    const size_t lds = sizeof(double) * (size_t)rb_rows;
+    const int nstrips = (rows + strip_rows - 1) / strip_rows;
+    const int nwg = (nstrips + kSweepWaves - 1) / kSweepWaves;
+    const size_t lds = sizeof(double) * (size_t)strip_rows * kSweepWaves;
     if (per_launch <= 0)
-        per_launch = nrb;
-    for (int first = 0; first < nrb; first += per_launch) {
-        const unsigned grid = (unsigned)(nrb - first < per_launch ? nrb - first : per_launch);
-        hipLaunchKernelGGL(csr_colsweep, dim3(grid), dim3(kSweepBlock), lds, stream, blk_ptr, e_col, e_val, e_row, x, y, rows,
-                           rb_rows, first);
+        per_launch = nwg;
+    static const int env_g = [] {
+        const char *e = getenv("SMVP_SWEEP_G");  // development switch: chunks in flight per wavefront (1, 2, 4)
+        return e ? atoi(e) : 0;
+    }();
+    const int g = env_g ? env_g : 1;
+    for (int first = 0; first < nwg; first += per_launch) {
+        const unsigned grid = (unsigned)(nwg - first < per_launch ? nwg - first : per_launch);
+#define SMVP_SWEEP(GG)                                                                                                   \
+    hipLaunchKernelGGL(csr_colsweep<GG>, dim3(grid), dim3(kSweepBlock), lds, stream, strip_ptr, e_col, e_val, e_row, x, y, \
+                       rows, strip_rows, nstrips, first)
+        if (g == 4)
+            SMVP_SWEEP(4);
+        else if (g == 2)
+            SMVP_SWEEP(2);
+        else
+            SMVP_SWEEP(1);
+#undef SMVP_SWEEP
     }
+    return hipGetLastError();
+}
+
+// How scattered are the gathers of a CSR matrix?  Sample s of `samples` looks at kSpreadSpan consecutive entries --
+// what one XCD's turn of 64 tiles of the tile kernel gathers -- and counts the distinct 128-byte lines of x they touch,
+// by linear counting: every line sets one hashed bit of a 512 Kbit LDS map; the host turns the number of set bits into
+// the estimate (engine: csr_gather_spread).  A count near the number of entries means that nearly every gather pulls
+// its own line through the L2: the matrix is one for the column sweep.
+__global__ __launch_bounds__(1024) void csr_line_spread(const int *__restrict__ col_ind, long long nnz, int samples,
+                                                        int *__restrict__ set_bits)
+{
+    constexpr int WORDS = 16 * 1024;  // 512 Kbit
+    __shared__ unsigned map[WORDS];
+    __shared__ int total;
+    for (int i = threadIdx.x; i < WORDS; i += 1024)
+        map[i] = 0u;
+    if (threadIdx.x == 0)
+        total = 0;
+    __syncthreads();
+    const long long first = samples > 1 ? (nnz - kSpreadSpan) / (samples - 1) * blockIdx.x : 0;
+    for (int i = threadIdx.x; i < kSpreadSpan; i += 1024) {
+        const long long j = first + i;
+        if (j < nnz) {
+            const unsigned line = (unsigned)col_ind[j] >> 4;
+            const unsigned h = (line * 2654435761u) >> (32 - 19);
+            atomicOr(&map[h >> 5], 1u << (h & 31));
+        }
+    }
+    __syncthreads();
+    int n = 0;
+    for (int i = threadIdx.x; i < WORDS; i += 1024)
+        n += __popc(map[i]);
+    atomicAdd(&total, n);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        set_bits[blockIdx.x] = total;
+}
+
+hipError_t launch_csr_line_spread(const int *col_ind, long long nnz, int samples, int *set_bits, hipStream_t stream)
+{
+    if (samples <= 0 || nnz < kSpreadSpan)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(csr_line_spread, dim3(samples), dim3(1024), 0, stream, col_ind, nnz, samples, set_bits);
     return hipGetLastError();
 }
 

@@ -67,7 +67,7 @@ EXPORTS = [
     "smvp_cache_write_csr", "smvp_cache_read_header", "smvp_cache_read_csr", "smvp_coo_from_csr",
     "smvp_csr_from_coo", "smvp_tjds_from_coo", "smvp_csr_from_coo_device", "smvp_tjds_from_coo_device",
     "smvp_device_count", "smvp_device_info",
-    "smvp_csr_create", "smvp_csr_set_kernel", "smvp_csr_get_kernel", "smvp_csr_spmv",
+    "smvp_csr_create", "smvp_csr_set_kernel", "smvp_csr_get_kernel", "smvp_csr_gather_spread", "smvp_csr_spmv",
     "smvp_csr_describe", "smvp_csr_destroy",
     "smvp_tjds_create", "smvp_tjds_set_x", "smvp_tjds_zero_y", "smvp_tjds_spmv",
     "smvp_tjds_set_ref_quirks", "smvp_tjds_set_mode", "smvp_tjds_set_tile", "smvp_tjds_describe", "smvp_tjds_destroy",
@@ -94,6 +94,7 @@ def lib():
         L.smvp_csr_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, vp, vp, vp, ci, vp]
         L.smvp_csr_set_kernel.argtypes = [vp, ci, ci]
         L.smvp_csr_get_kernel.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
+        L.smvp_csr_gather_spread.argtypes = [vp, C.POINTER(C.c_double)]
         L.smvp_csr_spmv.argtypes = [vp, vp, vp, vp]
         L.smvp_csr_describe.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double)]
         L.smvp_csr_destroy.argtypes = [vp]
@@ -403,6 +404,12 @@ class CsrMatrix:
         k, p = C.c_int(), C.c_int()
         _check(lib().smvp_csr_get_kernel(self._h, C.byref(k), C.byref(p)), "smvp_csr_get_kernel")
         return k.value, p.value
+
+    def gather_spread(self):
+        """Share of the gathers that pull their own line of x (what AUTO's choice of the column sweep rests on); -1: not sampled."""
+        v = C.c_double()
+        _check(lib().smvp_csr_gather_spread(self._h, C.byref(v)), "smvp_csr_gather_spread")
+        return v.value
 
     def spmv(self, x, y, stream=None):
         """y = A x, asynchronous on `stream`; x, y are torch CUDA float64 tensors."""

@@ -113,7 +113,7 @@ def test_csr_sample_matrices_general_x(torch, name, kernel, param):
     x = np.random.default_rng(67890).random(n)
     ref = ob.csr_spmv(row_ptr, col_ind, val, x)
     y = gpu_csr(torch, m, n, row_ptr, col_ind, val, x, kernel, param)
-    assert_close(y, ref, row_scale(row_ptr, col_ind, val, x))
+    assert_close(y, ref, row_scale(row_ptr, col_ind, val, x), exact=kernel == sm.CSR_KERNEL_COLSWEEP)   # sweep: serial order
 
 
 def test_stream_kernel_is_bitwise_serial_on_short_rows(torch):
@@ -139,46 +139,81 @@ def test_stream_kernel_is_bitwise_serial_on_short_rows(torch):
 
 
 def test_colsweep_on_scattered_columns(torch):
-    """The opt-in column-swept kernel on a config-4-shaped matrix (uniform columns over an operand larger than L2):
-    same product as the tile kernel within the bound (its LDS atomics add in no fixed order), row-block heights and
-    generations as planned, AUTO never picks it."""
+    """The column-swept kernel on a config-4-shaped matrix (uniform columns over an operand larger than L2): AUTO picks
+    it from its create-time estimate of the gather spread; every row is summed in ascending column order, so the result
+    is bit for bit the serial loop's (main-cli.c:410-416) and the same from run to run, whatever the strip height."""
     rows, cols = 700_000, 3_000_000
     row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_UNIFORM, 2024, cols, cols, 32, 0, rows)
     x = np.random.default_rng(9).random(cols)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, x)
     A = sm.CsrMatrix(rows, cols, row_ptr, col_ind, val)
-    assert A.get_kernel()[0] == sm.CSR_KERNEL_STREAM
+    assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, 2048)      # 700 K rows: 2048 per workgroup leaves >= 256 (342)
     dx = dev(torch, x)
     dy = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
     A.spmv(dx, dy)
     torch.cuda.synchronize()
-    y_tile = dy.cpu().numpy()
-    scale = row_scale(row_ptr, col_ind, val, x)
-    assert_close(y_tile, ob.csr_spmv(row_ptr, col_ind, val, x), scale)
-    for rb, want in ((0, 2048), (8192, 8192), (4096, 4096)):      # 700 K rows: 2048 leaves >= 256 blocks (342)
-        A.set_kernel(sm.CSR_KERNEL_COLSWEEP, rb)
-        assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, want) and A.describe()[0] == "csr_colsweep"
-        dy.fill_(float("nan"))
-        A.spmv(dx, dy)
-        torch.cuda.synchronize()
-        assert_close(dy.cpu().numpy(), y_tile, scale)
-    with pytest.raises(sm.SmvpError):
-        A.set_kernel(sm.CSR_KERNEL_COLSWEEP, 3000)
-    A.set_kernel(sm.CSR_KERNEL_AUTO, 0)                       # back to the tile kernel, plan rebuilt
+    assert np.array_equal(dy.cpu().numpy(), ref)
+    A.set_kernel(sm.CSR_KERNEL_STREAM, 0)
     dy.fill_(float("nan"))
     A.spmv(dx, dy)
     torch.cuda.synchronize()
-    assert np.array_equal(dy.cpu().numpy(), y_tile)
+    assert np.array_equal(dy.cpu().numpy(), ref)                  # 32 entries per row: the tile kernel is serial too
+    for rb, want in ((0, 2048), (8192, 8192), (4096, 4096), (1024, 1024)):
+        A.set_kernel(sm.CSR_KERNEL_COLSWEEP, rb)
+        assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, want) and A.describe()[0] == "csr_colsweep"
+        for _ in range(2):
+            dy.fill_(float("nan"))
+            A.spmv(dx, dy)
+            torch.cuda.synchronize()
+            assert np.array_equal(dy.cpu().numpy(), ref)
+    with pytest.raises(sm.SmvpError):
+        A.set_kernel(sm.CSR_KERNEL_COLSWEEP, 3000)
+    A.set_kernel(sm.CSR_KERNEL_AUTO, 0)                       # AUTO again: the sweep, plan rebuilt
+    assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, 2048)
+    dy.fill_(float("nan"))
+    A.spmv(dx, dy)
+    torch.cuda.synchronize()
+    assert np.array_equal(dy.cpu().numpy(), ref)
     A.close()
     # through the reference-shaped entry point too
     coo = sm.make_coo(np.repeat(np.arange(2000), 32), col_ind[:64000] % 2000, val[:64000])
     y1, _, _ = sm.csr_compute(coo, 2000, 2000, iters=3, kernel=sm.CSR_KERNEL_COLSWEEP)
     y0, _, _ = sm.csr_compute(coo, 2000, 2000, iters=3)
-    rp0, ci0, v0 = sm.csr_from_coo(coo, 2000)
-    assert_close(y1, y0, row_scale(rp0, ci0, v0, np.ones(2000)))
+    assert np.array_equal(y1, y0)
+
+
+def test_colsweep_rows_that_meet_in_a_chunk(torch):
+    """Entries of one row that arrive in the same 256-entry chunk of a strip's stream take turns; from the 31st on
+    they are added lane by lane.  Dense rows in a narrow band of columns (and a few duplicate columns, which Matrix
+    Market allows and the serial loop adds in input order) put whole chunks on that path: still the serial bits."""
+    rng = np.random.default_rng(77)
+    lens = [300, 1, 0, 257, 64, 31, 32, 33, 700] * 40 + [2] * 3000
+    rows, cols = len(lens), 1024
+    row_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col_ind = np.concatenate([np.sort(rng.integers(0, cols, n)) for n in lens]).astype(np.int32)   # with repeats
+    val = rng.uniform(-1, 1, len(col_ind))
+    x = rng.random(cols)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+    for rb in (0, 1024, 8192):
+        y = gpu_csr(torch, rows, cols, row_ptr, col_ind, val, x, sm.CSR_KERNEL_COLSWEEP, rb)
+        assert np.array_equal(y, ref)
 
 
 def test_auto_plan_choice(torch):
-    """AUTO: owner-completes tiles by default, the carry form when some row is extremely long; never the vector kernel."""
+    """AUTO: owner-completes tiles by default, the carry form when some row is extremely long; never the vector kernel;
+    the column sweep only for large matrices whose gathers scatter over an operand much larger than the L2."""
+    # a band of 8 entries per row, 32 M entries over a 32 MB operand: neighbouring gathers share lines -> tile kernel;
+    # the SURVEY 8(d) random model (39 % of its entries uniform over the operand: spread about 0.4) -> tile kernel
+    n = 4_000_000
+    band = ((np.arange(n, dtype=np.int64)[:, None] + np.arange(-4, 4)) % n).astype(np.int32)
+    band.sort(axis=1)
+    A = sm.CsrMatrix(n, n, (np.arange(n + 1, dtype=np.int64) * 8).astype(np.int32), band.ravel(), np.ones(8 * n))
+    assert A.get_kernel()[0] == sm.CSR_KERNEL_STREAM
+    A.close()
+    row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_MEMPLUS_SHAPED, 5, 1 << 22, 1 << 22)
+    A = sm.CsrMatrix(1 << 22, 1 << 22, row_ptr, col_ind, val)
+    assert A.get_kernel()[0] == sm.CSR_KERNEL_STREAM
+    A.close()
     rng = np.random.default_rng(11)
     for lens, want in (([5] * 300000, sm.CSR_KERNEL_STREAM), ([3] * 500 + [40000] + [2] * 500, sm.CSR_KERNEL_STREAM_CARRY),
                        ([128] * 300, sm.CSR_KERNEL_STREAM)):
@@ -320,7 +355,7 @@ def test_csr_edge_cases(torch, case, kernel, param):
     x = rng.random(cols)
     ref = ob.csr_spmv(row_ptr, col_ind, val, x)
     y = gpu_csr(torch, rows, cols, row_ptr, col_ind, val, x, kernel, param)
-    assert_close(y, ref, row_scale(row_ptr, col_ind, val, x))
+    assert_close(y, ref, row_scale(row_ptr, col_ind, val, x), exact=kernel == sm.CSR_KERNEL_COLSWEEP)
 
 
 @pytest.mark.parametrize("name", SAMPLES)
@@ -1124,13 +1159,14 @@ def test_device_timing_agrees_with_events_and_is_the_default_for_small_launches(
 def test_config4_full_size_properties(torch):
     """BASELINE config 4 at its full size: 10 M x 10 M, 32 entries per row (320 M entries, 3.8 GB).
 
-    Size-independent properties only: y(ones) = row sums (independent numpy computation), linearity, agreement of the
-    two tile kernels, run-to-run bit equality, and the oracle on the first 20 000 rows."""
+    AUTO picks the column sweep here.  Size-independent properties only: y(ones) = row sums (independent numpy
+    computation), linearity, agreement of the sweep with the two tile kernels -- bit for bit, all three sum these rows in
+    serial order --, run-to-run bit equality, and the oracle on the first 20 000 rows."""
     M = 10_000_000
     row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_UNIFORM, 2024, M, M, param=32)
     assert len(col_ind) == 320_000_000
     A = sm.CsrMatrix(M, M, row_ptr, col_ind, val)
-    assert A.get_kernel()[0] == sm.CSR_KERNEL_STREAM
+    assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, 8192)
     ones = torch.ones(M, dtype=torch.float64, device="cuda")
     y1, y2, ya, yb, yab = (torch.empty(M, dtype=torch.float64, device="cuda") for _ in range(5))
     A.spmv(ones, y1)
@@ -1148,13 +1184,14 @@ def test_config4_full_size_properties(torch):
     torch.cuda.synchronize()
     sc = torch.from_numpy(scale).cuda() * 2
     assert bool(((yab - (ya + yb)).abs() <= TOL * sc).all())
-    A.set_kernel(sm.CSR_KERNEL_STREAM_CARRY, 0)
-    A.spmv(xa, y2)
-    torch.cuda.synchronize()
-    assert bool(((ya - y2).abs() <= TOL * sc).all())
     k = 20_000
     ref = ob.csr_spmv(row_ptr[:k + 1].copy(), col_ind[:row_ptr[k]], val[:row_ptr[k]], xa.cpu().numpy())
-    assert np.array_equal(ya.cpu().numpy()[:k], ref)        # 32 entries per row: one lane, serial order, same bits
+    assert np.array_equal(ya.cpu().numpy()[:k], ref)        # ascending column order inside every row: the serial bits
+    for kernel in (sm.CSR_KERNEL_STREAM, sm.CSR_KERNEL_STREAM_CARRY):
+        A.set_kernel(kernel, 0)
+        A.spmv(xa, y2)
+        torch.cuda.synchronize()
+        assert torch.equal(ya, y2)                          # 32 entries per row: one lane, serial order, same bits
     A.close()
 
 

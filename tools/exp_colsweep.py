@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """The column-swept CSR kernel (SMVP_CSR_KERNEL_COLSWEEP) against the tile kernel on matrices with scattered columns.
 
-    python3 tools/exp_colsweep.py --workload uniform|random|random_far [--rows N --local-rows L] --rb 0,8192,4096
-uniform = BASELINE config 4 (optionally only the first L rows: one rank's block); random = the SURVEY 8(d) model;
+    python3 tools/exp_colsweep.py --workload uniform|random|random_far [--rows N --local-rows L --per-row P] --rb 0,8192,4096
+uniform = BASELINE config 4 (optionally only the first L rows: one rank's block; N columns, P entries per row);
+random = the SURVEY 8(d) model (N rows);
 random_far = its entries beyond distance 4096 through the sweep, the rest through the tile kernel.
 (The per-cell and thread-count variants recorded in profiles/r02_colsweep_measured.txt were run with earlier
 revisions of this tool and of the kernel.)
@@ -34,15 +35,16 @@ def main():
     ap.add_argument("--workload", default="uniform")
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--local-rows", type=int, default=0)
+    ap.add_argument("--per-row", type=int, default=32)
     ap.add_argument("--rb", default="0")
     a = ap.parse_args()
     import torch
     import smvp_toolkit_amd as sm
     if a.workload == "uniform":
         rows, cols = a.local_rows or a.rows, a.rows
-        rp, ci, v = sm.synth_csr(sm.SYNTH_UNIFORM, 2024, a.rows, a.rows, 32, 0, rows, threads=32)
+        rp, ci, v = sm.synth_csr(sm.SYNTH_UNIFORM, 2024, a.rows, a.rows, a.per_row, 0, rows, threads=32)
     else:
-        rows = cols = 1 << 24
+        rows = cols = a.rows if a.rows != 10_000_000 else 1 << 24
         rp, ci, v = sm.synth_csr(sm.SYNTH_MEMPLUS_SHAPED, 12345, rows, rows, 0, 0, rows, threads=32)
     nnz = int(rp[-1])
     alg = 12.0 * nnz + 4.0 * (rows + 1) + 8.0 * rows + 8.0 * cols
@@ -51,6 +53,8 @@ def main():
     y = torch.empty(rows, dtype=torch.float64, device="cuda")
     d_rp, d_ci, d_v = torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(v).cuda()
     A = sm.CsrMatrix(rows, cols, d_rp, d_ci, d_v)
+    print("# AUTO picks kernel %s; gather spread %.3f" % (A.get_kernel(), A.gather_spread()), flush=True)
+    A.set_kernel(sm.CSR_KERNEL_STREAM, 0)
     A.spmv(x, y, stream=st)
     torch.cuda.synchronize()
     y_ref = y.clone()
@@ -80,6 +84,10 @@ def main():
         S.spmv(x, y, stream=st)
         torch.cuda.synchronize()
         err = float((y - y_ref).abs().max() / y_ref.abs().max())
+        y2 = y.clone()
+        S.spmv(x, y, stream=st)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2), "not the same bits from run to run"
         ms = timeit(torch, lambda: S.spmv(x, y, stream=st))
         tot = ms + t_near
         print("colsweep rows/block %5d (asked %d): %.4f ms  %.1f G gathers/s  max err %.1e  |  whole product %.4f ms = %.1f %% of 8 TB/s" % (
