@@ -158,15 +158,15 @@ void free_sweep_plan(smvp_csr *h)
 // rb * (mean row length) entries in column order, 1024 per pass of its workgroup (256 per strip), so its window moves
 // 1024 * cols / (rb * mean) columns of x per pass: the taller the block, the slower the window and the better the
 // XCD's L2 holds what the resident workgroups gather -- but the launch should still have a few hundred workgroups.
-// So: the tallest of 8192 / 4096 / 2048 / 1024 rows (8192 rows = 64 KB of sums in LDS) that leaves >= 256 row blocks,
-// but never so short that a pass moves the window by more than ~1.3 MB.  All blocks start together when they are
-// resident at once, else in even generations of at most 256.  Measured on BASELINE config 4
-// (profiles/r02_colsweep_measured.txt): 10 M rows -> 8192 / 5 x 245: 2.40 ms (4096: 2.68); one rank's eighth,
-// 1.25 M rows -> 4096 / all 305: 0.413 ms (8192: 0.478, 2048: 0.490); a 312 K-row chunk -> 2048: 0.113 ms (1024: 0.144).
+// So: the tallest of 8192 / 4096 / 2048 / 1024 rows (8192 rows = 64 KB of sums in LDS) that leaves >= 128 workgroups,
+// but never so short that a pass moves the window by more than ~1.3 MB.  All workgroups start together when they are
+// resident at once, else in even generations of at most 256.  Measured on BASELINE config 4 (round 3, deterministic
+// kernel, tools/exp_colsweep.py): 10 M rows -> 8192 / 5 x 245: 2.25 ms (4096: 2.62); one rank's eighth, 1.25 M rows ->
+// 8192 / all 153: 0.44 ms (4096: 0.48); a 312 K-row chunk -> 2048 / all 153: 0.134 ms (1024: 0.169, 4096: 0.25).
 void choose_sweep_shape(int rows, int cols, int nnz, int want_rb, int *rb, int *per_launch)
 {
     int r = 8192;
-    while (r > 1024 && (rows + r - 1) / r < 256)
+    while (r > 1024 && (rows + r - 1) / r < 128)
         r >>= 1;
     const double mean = rows > 0 ? std::max(1.0, (double)nnz / rows) : 1.0;
     int floor_rb = 1024;
@@ -1265,6 +1265,8 @@ extern "C" int smvp_last_run_info(smvp_run_info_t *out)
 static int sharded_compute(bool tjds, const smvp_coo_t *coo, int rows, int cols, int nnz, int iters,
                            const smvp_run_opts_t *o, double *y, double *time_each_ms, smvp_time_stats_t *stats)
 {
+    if (o->timing == SMVP_TIMING_DEVICE)  // the in-kernel stamps time one launch of one GPU; a sharded product is several
+        return smvp::fail(SMVP_ERR_UNSUPPORTED, "device-side timing is not available with more than one GPU (use events)");
     smvp_sharded_t *h = nullptr;
     int rc;
     if (tjds) {

@@ -4,9 +4,12 @@
 // the matrix is cut into row blocks balanced by entries (smvp_partition_rows), GPU g
 // holds block g, all of x, and produces its slice of y; RCCL all-gathers over xGMI
 // assemble the full y on every GPU.  Each block is further cut into `chunks` row
-// chunks, each its own CSR / TJDS handle: the all-gather of chunk c (on the GPU's
-// communication stream) travels while chunk c+1 is being multiplied (on its compute
-// stream).  ncclAllGather wants equal counts, so a chunk goes onto the wire padded to
+// chunks, each its own CSR / TJDS handle: the all-gather of chunk c is put on the GPU's
+// communication stream right behind an event of chunk c's product, so it travels while
+// chunk c+1 is being multiplied on the compute stream.  With more than one GPU every GPU
+// has its own issuing thread (one communicator rank per thread, no grouped calls): the
+// launches of eight GPUs are not queued behind each other on one host thread.
+// ncclAllGather wants equal counts, so a chunk goes onto the wire padded to
 // the tallest chunk c of any GPU and one small kernel per GPU then copies the
 // gathered pieces to their rows of the full vector.
 // bench.py does the same with one process per GPU through torch.distributed; this
@@ -23,9 +26,11 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #define HIP_TRY(expr)                                                                       \
@@ -139,12 +144,38 @@ struct smvp_sharded {
     std::vector<ncclComm_t> comm;
     std::vector<unsigned long long *> d_norm;
     Rccl *rccl = nullptr;
+
+    // n > 1: one issuing thread per GPU, woken for every product (issue_product)
+    std::vector<std::thread> issuer;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    unsigned long long job = 0;
+    int job_allgather = 0, job_timed = 0, pending = 0;
+    bool quit = false;
+    std::vector<int> job_rc;
+    std::vector<std::string> job_err;
 };
+
+namespace {
+void stop_issuers(smvp_sharded *h)
+{
+    {
+        std::lock_guard<std::mutex> lock(h->mu);
+        h->quit = true;
+    }
+    h->cv_go.notify_all();
+    for (std::thread &t : h->issuer)
+        if (t.joinable())
+            t.join();
+    h->issuer.clear();
+}
+}  // namespace
 
 extern "C" void smvp_sharded_destroy(smvp_sharded_t *h)
 {
     if (!h)
         return;
+    stop_issuers(h);
     DeviceScope keep;
     for (int g = 0; g < (int)h->device.size(); ++g) {
         const size_t i = (size_t)g;
@@ -453,69 +484,120 @@ extern "C" int smvp_sharded_set_x(smvp_sharded_t *h, const double *x_host)
     return SMVP_OK;
 }
 
-// One product: on every GPU the chunk products in turn on its compute stream; allgather = SMVP_GATHER_OVERLAPPED: the
-// ncclAllGather of chunk c is issued on the communication streams as soon as every GPU has produced its chunk c,
-// while the later chunks are still being multiplied; SMVP_GATHER_AFTER: all gathers on the compute streams after all
-// products (nothing overlapped); 0: local products only.  Then one kernel per GPU copies the gathered pieces to
-// their rows of the full vector.  `timed` brackets all of it with an event pair per GPU; TJDS chunks that need a
-// cleared y get it first, outside the pair (main-cli.c:1008).
+namespace {
+
+// What GPU g contributes to one product: its chunk products in turn on its compute stream and, by `allgather`, its
+// side of the exchange of y.  SMVP_GATHER_OVERLAPPED: the all-gather of chunk c goes onto the communication stream
+// right behind the event of chunk c's product -- before chunk c + 1 is even launched -- so chunk c travels while the
+// later chunks are multiplied; SMVP_GATHER_AFTER: all gathers on the compute stream after all products (nothing
+// overlapped); 0: local products only.  Then one kernel copies the gathered pieces to their rows of the full vector.
+// `timed` brackets all of it with an event pair; TJDS chunks that need a cleared y get it first, outside the pair
+// (main-cli.c:1008).  Runs on GPU g's issuing thread (the caller's own when there is one GPU): every communicator
+// rank is driven by one thread, the ranks' calls come in the same order, so no grouping is needed.
+int issue_product(smvp_sharded *h, size_t g, int allgather, int timed)
+{
+    const size_t C = (size_t)h->chunks;
+    const bool overlap = allgather == SMVP_GATHER_OVERLAPPED;
+    HIP_TRY(hipSetDevice(h->device[g]));
+    if (h->format == 1)
+        for (size_t c = 0; c < C; ++c)
+            if (int rc = smvp_tjds_zero_y(h->tjds[g * C + c], h->d_y_local[g] + h->loff[c], h->stream[g]))
+                return rc;
+    if (timed)
+        HIP_TRY(hipEventRecord(h->ev0[g], h->stream[g]));
+    auto gather = [&](size_t c, hipStream_t st) -> int {
+        const ncclResult_t nr = h->rccl->AllGather(h->d_y_local[g] + h->loff[c], h->d_wire[g] + h->woff[c], (size_t)h->pad[c],
+                                                   ncclDouble, h->comm[g], st);
+        if (nr != ncclSuccess)
+            return smvp::fail(SMVP_ERR_HIP, "ncclAllGather failed: %s", h->rccl->GetErrorString(nr));
+        return SMVP_OK;
+    };
+    for (size_t c = 0; c < C; ++c) {
+        double *yc = h->d_y_local[g] + h->loff[c];
+        const int rc = h->format == 0 ? smvp_csr_spmv(h->csr[g * C + c], h->d_x[g], yc, h->stream[g])
+                                      : smvp_tjds_spmv(h->tjds[g * C + c], yc, h->stream[g]);
+        if (rc != SMVP_OK)
+            return rc;
+        if (overlap) {
+            HIP_TRY(hipEventRecord(h->ev_chunk[g * C + c], h->stream[g]));
+            HIP_TRY(hipStreamWaitEvent(h->comm_stream[g], h->ev_chunk[g * C + c], 0));
+            if (int grc = gather(c, h->comm_stream[g]))
+                return grc;
+        }
+    }
+    if (allgather) {
+        if (!overlap)
+            for (size_t c = 0; c < C; ++c)
+                if (int grc = gather(c, h->stream[g]))
+                    return grc;
+        if (overlap) {
+            HIP_TRY(hipEventRecord(h->ev_gathered[g], h->comm_stream[g]));
+            HIP_TRY(hipStreamWaitEvent(h->stream[g], h->ev_gathered[g], 0));
+        }
+        if (h->rows > 0) {
+            hipLaunchKernelGGL(place_gathered, dim3((unsigned)((h->rows + 255) / 256)), dim3(256), 0, h->stream[g], h->d_wire[g],
+                               h->d_y_full[g], h->d_seg[g], h->nseg, h->rows);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    if (timed)
+        HIP_TRY(hipEventRecord(h->ev1[g], h->stream[g]));
+    return SMVP_OK;
+}
+
+void issuer_main(smvp_sharded *h, size_t g)
+{
+    unsigned long long seen = 0;
+    for (;;) {
+        int allgather, timed;
+        {
+            std::unique_lock<std::mutex> lock(h->mu);
+            h->cv_go.wait(lock, [&] { return h->quit || h->job != seen; });
+            if (h->quit)
+                return;
+            seen = h->job;
+            allgather = h->job_allgather, timed = h->job_timed;
+        }
+        const int rc = issue_product(h, g, allgather, timed);
+        {
+            std::lock_guard<std::mutex> lock(h->mu);
+            h->job_rc[g] = rc;
+            h->job_err[g] = rc == SMVP_OK ? "" : smvp_last_error();
+            --h->pending;
+        }
+        h->cv_done.notify_all();
+    }
+}
+
+}  // namespace
+
+// One product, asynchronous (see issue_product); returns when every GPU's launches and collectives are enqueued.
 extern "C" int smvp_sharded_spmv(smvp_sharded_t *h, int allgather, int timed)
 {
     if (!h || allgather < 0 || allgather > SMVP_GATHER_AFTER)
         return smvp::fail(SMVP_ERR_INVALID, "smvp_sharded_spmv: bad argument");
-    DeviceScope keep;
-    const size_t n = (size_t)h->n, C = (size_t)h->chunks;
-    const bool overlap = allgather == SMVP_GATHER_OVERLAPPED;
-    for (size_t g = 0; g < n; ++g) {
-        HIP_TRY(hipSetDevice(h->device[g]));
-        if (h->format == 1)
-            for (size_t c = 0; c < C; ++c)
-                if (int rc = smvp_tjds_zero_y(h->tjds[g * C + c], h->d_y_local[g] + h->loff[c], h->stream[g]))
-                    return rc;
-        if (timed)
-            HIP_TRY(hipEventRecord(h->ev0[g], h->stream[g]));
-        for (size_t c = 0; c < C; ++c) {
-            double *yc = h->d_y_local[g] + h->loff[c];
-            const int rc = h->format == 0 ? smvp_csr_spmv(h->csr[g * C + c], h->d_x[g], yc, h->stream[g])
-                                          : smvp_tjds_spmv(h->tjds[g * C + c], yc, h->stream[g]);
-            if (rc != SMVP_OK)
-                return rc;
-            if (overlap) {
-                HIP_TRY(hipEventRecord(h->ev_chunk[g * C + c], h->stream[g]));
-                HIP_TRY(hipStreamWaitEvent(h->comm_stream[g], h->ev_chunk[g * C + c], 0));
-            }
-        }
+    const size_t n = (size_t)h->n;
+    if (n == 1) {
+        DeviceScope keep;
+        return issue_product(h, 0, allgather, timed);
     }
-    if (allgather) {
-        for (size_t c = 0; c < C; ++c) {
-            ncclResult_t nr = h->rccl->GroupStart();
-            for (size_t g = 0; g < n && nr == ncclSuccess; ++g)
-                nr = h->rccl->AllGather(h->d_y_local[g] + h->loff[c], h->d_wire[g] + h->woff[c], (size_t)h->pad[c], ncclDouble,
-                                        h->comm[g], overlap ? h->comm_stream[g] : h->stream[g]);
-            const ncclResult_t ne = h->rccl->GroupEnd();
-            if (nr == ncclSuccess)
-                nr = ne;
-            if (nr != ncclSuccess)
-                return smvp::fail(SMVP_ERR_HIP, "ncclAllGather failed: %s", h->rccl->GetErrorString(nr));
-        }
-        for (size_t g = 0; g < n; ++g) {
-            HIP_TRY(hipSetDevice(h->device[g]));
-            if (overlap) {
-                HIP_TRY(hipEventRecord(h->ev_gathered[g], h->comm_stream[g]));
-                HIP_TRY(hipStreamWaitEvent(h->stream[g], h->ev_gathered[g], 0));
-            }
-            if (h->rows > 0) {
-                hipLaunchKernelGGL(place_gathered, dim3((unsigned)((h->rows + 255) / 256)), dim3(256), 0, h->stream[g],
-                                   h->d_wire[g], h->d_y_full[g], h->d_seg[g], h->nseg, h->rows);
-                HIP_TRY(hipGetLastError());
-            }
-        }
+    if (h->issuer.empty()) {
+        h->job_rc.assign(n, SMVP_OK);
+        h->job_err.assign(n, "");
+        for (size_t g = 0; g < n; ++g)
+            h->issuer.emplace_back(issuer_main, h, g);
     }
-    if (timed)
-        for (size_t g = 0; g < n; ++g) {
-            HIP_TRY(hipSetDevice(h->device[g]));
-            HIP_TRY(hipEventRecord(h->ev1[g], h->stream[g]));
-        }
+    {
+        std::unique_lock<std::mutex> lock(h->mu);
+        h->job_allgather = allgather, h->job_timed = timed;
+        h->pending = (int)n;
+        ++h->job;
+        h->cv_go.notify_all();
+        h->cv_done.wait(lock, [&] { return h->pending == 0; });
+    }
+    for (size_t g = 0; g < n; ++g)
+        if (h->job_rc[g] != SMVP_OK)
+            return smvp::fail(h->job_rc[g], "GPU %d: %s", h->device[g], h->job_err[g].c_str());
     return SMVP_OK;
 }
 
