@@ -195,6 +195,9 @@ int smvp_csr_spmv(smvp_csr_t *h, const double *d_x, double *d_y, void *stream);
 /* Name of the dominant kernel symbol of the current plan and its algorithmic
  * byte count per launch: 12*nnz + 4*(rows+1) + 8*cols + 8*rows. */
 int smvp_csr_describe(const smvp_csr_t *h, char *kernel_name, size_t cap, double *alg_bytes);
+/* Kernel launches per product of the current plan: 1, except STREAM_CARRY (2: tiles + carry fix-up) and COLSWEEP
+ * (its workgroups start in generations that are resident together; config 4 on one GPU: 5). */
+int smvp_csr_plan_launches(const smvp_csr_t *h, int *launches);
 void smvp_csr_destroy(smvp_csr_t *h);
 
 /* Device-side half of smvp_tjds_compute (main-cli.c:756-763,944-967): val,

@@ -573,7 +573,7 @@ extern "C" int smvp_csr_describe(const smvp_csr_t *h, char *kernel_name, size_t 
         return smvp::fail(SMVP_ERR_INVALID, "null handle");
     if (kernel_name && cap) {
         if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP)
-            snprintf(kernel_name, cap, "csr_colsweep");
+            snprintf(kernel_name, cap, "csr_colsweep<%d>", smvp::sweep_chunks_in_flight(h->sweep_rb / smvp::kSweepWaves));
         else if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
             snprintf(kernel_name, cap, "csr_vector_rows<%d>", h->lanes_per_row);
         else if (h->kernel == SMVP_CSR_KERNEL_STREAM)
@@ -583,6 +583,21 @@ extern "C" int smvp_csr_describe(const smvp_csr_t *h, char *kernel_name, size_t 
     }
     if (alg_bytes)
         *alg_bytes = 12.0 * h->nnz + 4.0 * (h->rows + 1.0) + 8.0 * h->cols + 8.0 * h->rows;
+    return SMVP_OK;
+}
+
+// kernel launches one product of the current plan takes (the column sweep starts its workgroups in generations)
+extern "C" int smvp_csr_plan_launches(const smvp_csr_t *h, int *launches)
+{
+    if (!h || !launches)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_plan_launches: bad argument");
+    *launches = 1;
+    if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP && h->sweep_rb > 0 && h->sweep_per_launch > 0) {
+        const int nwg = (h->rows + h->sweep_rb - 1) / h->sweep_rb;
+        *launches = std::max(1, (nwg + h->sweep_per_launch - 1) / h->sweep_per_launch);
+    } else if (h->kernel == SMVP_CSR_KERNEL_STREAM_CARRY && h->ntiles > 1) {
+        *launches = 2;
+    }
     return SMVP_OK;
 }
 

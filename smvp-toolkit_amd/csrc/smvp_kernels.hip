@@ -1059,6 +1059,17 @@ __global__ __launch_bounds__(kSweepBlock) void csr_colsweep(
         __builtin_nontemporal_store(sums[i], &y[r0 + i]);
 }
 
+// Chunks in flight per wavefront.  Strips of 2048 rows leave room for two workgroups per CU (64 KB of sums each):
+// two chunks in flight make up for the missing wavefronts (config 4: 2.25 against 2.55 ms; one rank's eighth
+// 0.44 against 0.50); shorter strips run more wavefronts per CU and do best with one (0.134 / 0.144 / 0.160 ms
+// for 1 / 2 / 4 on a 312 K-row chunk).  SMVP_SWEEP_G=1|2|4 overrides (development switch).
+int sweep_chunks_in_flight(int strip_rows)
+{
+    const char *env = getenv("SMVP_SWEEP_G");
+    const int env_g = env ? atoi(env) : 0;
+    return env_g == 1 || env_g == 2 || env_g == 4 ? env_g : (strip_rows >= 2048 ? 2 : 1);
+}
+
 hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, const double *e_val, const unsigned short *e_row,
                                const double *x, double *y, int rows, int strip_rows, int per_launch, hipStream_t stream)
 {
@@ -1069,13 +1080,7 @@ hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, con
     const size_t lds = sizeof(double) * (size_t)strip_rows * kSweepWaves;
     if (per_launch <= 0)
         per_launch = nwg;
-    // Chunks in flight per wavefront.  Strips of 2048 rows leave room for two workgroups per CU (64 KB of sums each):
-    // two chunks in flight make up for the missing wavefronts (config 4: 2.25 against 2.55 ms; one rank's eighth
-    // 0.44 against 0.50); shorter strips run more wavefronts per CU and do best with one (0.134 / 0.144 / 0.160 ms
-    // for 1 / 2 / 4 on a 312 K-row chunk).  SMVP_SWEEP_G=1|2|4 overrides (development switch).
-    const char *env = getenv("SMVP_SWEEP_G");
-    const int env_g = env ? atoi(env) : 0;
-    const int g = env_g ? env_g : (strip_rows >= 2048 ? 2 : 1);
+    const int g = sweep_chunks_in_flight(strip_rows);
     for (int first = 0; first < nwg; first += per_launch) {
         const unsigned grid = (unsigned)(nwg - first < per_launch ? nwg - first : per_launch);
 #define SMVP_SWEEP(GG)                                                                                                   \

@@ -68,7 +68,7 @@ EXPORTS = [
     "smvp_csr_from_coo", "smvp_tjds_from_coo", "smvp_csr_from_coo_device", "smvp_tjds_from_coo_device",
     "smvp_device_count", "smvp_device_info",
     "smvp_csr_create", "smvp_csr_set_kernel", "smvp_csr_get_kernel", "smvp_csr_gather_spread", "smvp_csr_spmv",
-    "smvp_csr_describe", "smvp_csr_destroy",
+    "smvp_csr_describe", "smvp_csr_plan_launches", "smvp_csr_destroy",
     "smvp_tjds_create", "smvp_tjds_set_x", "smvp_tjds_zero_y", "smvp_tjds_spmv",
     "smvp_tjds_set_ref_quirks", "smvp_tjds_set_mode", "smvp_tjds_set_tile", "smvp_tjds_describe", "smvp_tjds_destroy",
     "smvp_shard_opts_default", "smvp_csr_sharded_create", "smvp_csr_sharded_create_ex", "smvp_tjds_sharded_create",
@@ -97,6 +97,7 @@ def lib():
         L.smvp_csr_gather_spread.argtypes = [vp, C.POINTER(C.c_double)]
         L.smvp_csr_spmv.argtypes = [vp, vp, vp, vp]
         L.smvp_csr_describe.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double)]
+        L.smvp_csr_plan_launches.argtypes = [vp, C.POINTER(ci)]
         L.smvp_csr_destroy.argtypes = [vp]
         L.smvp_csr_destroy.restype = None
         L.smvp_tjds_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, ci, vp, vp, vp, vp, ci]
@@ -404,6 +405,12 @@ class CsrMatrix:
         k, p = C.c_int(), C.c_int()
         _check(lib().smvp_csr_get_kernel(self._h, C.byref(k), C.byref(p)), "smvp_csr_get_kernel")
         return k.value, p.value
+
+    def launches(self):
+        """Kernel launches per product of the current plan."""
+        n = C.c_int()
+        _check(lib().smvp_csr_plan_launches(self._h, C.byref(n)), "smvp_csr_plan_launches")
+        return n.value
 
     def gather_spread(self):
         """Share of the gathers that pull their own line of x (what AUTO's choice of the column sweep rests on); -1: not sampled."""

@@ -160,7 +160,7 @@ def test_colsweep_on_scattered_columns(torch):
     assert np.array_equal(dy.cpu().numpy(), ref)                  # 32 entries per row: the tile kernel is serial too
     for rb, want in ((0, 4096), (8192, 8192), (2048, 2048), (1024, 1024)):
         A.set_kernel(sm.CSR_KERNEL_COLSWEEP, rb)
-        assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, want) and A.describe()[0] == "csr_colsweep"
+        assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, want) and A.describe()[0].startswith("csr_colsweep<")
         for _ in range(2):
             dy.fill_(float("nan"))
             A.spmv(dx, dy)
@@ -680,6 +680,15 @@ def test_bench_script_runs_small(torch):
     assert "error" not in c5 and c5["y_equals_reference_report"] and 0 < c5["csr_ms_per_step"] < c5["csr_then_tjds_ms_per_step"]
     sm_ = j["extra"]["sample_matrices"]["memplus.mtx"]
     assert sm_["csr_avg_ms"] < sm_["csr_avg_ms_event_pairs"] and sm_["csr_agrees_with_cpu"] and sm_["tjds_agrees_with_cpu"]
+    # what the driver keeps: every other kernel priced inside `roofline`, and the C ABI's own sharded product timed
+    o = j["roofline"]["others"]
+    for key in ("tjds", "config4", "config4_c_layer", "pwt_tiled_csr", "pwt_tiled_tjds", "survey_random_model",
+                "sample_matrices_us_per_product"):
+        assert key in o and "error" not in o[key], key
+    assert 0 < o["tjds"]["frac"] < 1 and 0 < o["config4"]["frac"] < 1 and o["config4"]["bit_identical_run_to_run"]
+    cl = o["config4_c_layer"]
+    assert cl["n_gpus"] == 1 and all(cl["chunks_%d" % c][f]["event_ms"] > 0 for c in (1, 4)
+                                     for f in ("products_only", "products_then_allgather", "overlapped"))
 
 
 # --------------------------------------------------- device-side format conversion

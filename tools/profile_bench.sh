@@ -9,7 +9,7 @@ TAG=${1:-r01}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p "$OUT"
-ARGS="--no-random-model --no-tjds --no-cpu-baseline --no-samples --no-config4 --no-pwt-tiled ${BENCH_ARGS:-}"
+ARGS="--no-live-traffic --no-c-layer --no-random-model --no-tjds --no-cpu-baseline --no-samples --no-config4 --no-pwt-tiled ${BENCH_ARGS:-}"
 PAT=${PAT:-csr_stream_owner<4, 0}   # kernel-name substring the PMC summary is taken over
 python3 $R/bench.py --steps 100 --warmup 10 $ARGS > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "bench failed"; tail -5 "$OUT/bench.err"; exit 1; }
 cd /tmp; export TMPDIR=/tmp
