@@ -233,6 +233,14 @@ enum {
 };
 int smvp_tjds_set_mode(smvp_tjds_t *h, int mode);
 int smvp_tjds_set_tile(smvp_tjds_t *h, int entries_per_tile); /* ROW_GATHER: 256, 1024 or 2048 entries per workgroup (re-plans) */
+/* ROW_GATHER's value cache.  Far down the jagged diagonals only the long columns are left: neighbours in val are
+ * entries of unrelated rows, and a 128-byte line of val would be pulled through the L2 once for each of them.  The plan
+ * therefore keeps a second copy of the values of every val line whose 16 entries belong to `min_tiles` or more
+ * different tiles (default 8), stored tile by tile and read coalesced; all other values are read from val itself.
+ * 0 = no cache (every value from val).  The sums and their order do not depend on it.  A handle over adopted device
+ * arrays (SMVP_MEM_DEVICE) must be re-created, or this called again, after val has been changed in place. */
+int smvp_tjds_set_value_cache(smvp_tjds_t *h, int min_tiles);
+int smvp_tjds_get_value_cache(const smvp_tjds_t *h, int *min_tiles, long long *cached_entries);
 /* Reference-defect emulation for parity with the committed TJDS reports
  * (diagonal count from original column 0, missing terminator, operand indexed
  * by row: main-cli.c:865,951-966,1018).  A host-side edit of the launch plan of the atomic kernel. */

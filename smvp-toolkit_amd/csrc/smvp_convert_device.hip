@@ -297,14 +297,56 @@ __global__ __launch_bounds__(256) void positions_to_columns(const int *__restric
 
 namespace {
 
-__global__ __launch_bounds__(256) void window_keys(const int *__restrict__ pos, int nnz, int tile, u64 *__restrict__ key,
-                                                   unsigned *__restrict__ slot)
+// where[p] = place e of TJDS position p in the row-major stream (pos[e] = p)
+__global__ __launch_bounds__(256) void invert_positions(const int *__restrict__ pos, int nnz, int *__restrict__ where)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < nnz)
+        where[pos[e]] = e;
+}
+
+// One thread per 128-byte line of val (16 positions): how many different tiles of the row-major stream do its entries
+// belong to?  A line whose entries scatter over `min_tiles` tiles or more would be pulled through the L2 once per tile
+// for 8 useful bytes each time (the long columns' entries far down the jagged diagonals: neighbours in TJDS order,
+// unrelated rows); its entries are marked and get their values from the tiles' own cache instead.
+__global__ __launch_bounds__(256) void mark_scattered_lines(const int *__restrict__ where, int nnz, int tile, int min_tiles,
+                                                            unsigned char *__restrict__ line_flag)
+{
+    const int line = blockIdx.x * 256 + threadIdx.x;
+    const long long p0 = (long long)line * 16;
+    if (p0 >= nnz)
+        return;
+    int owner[16];
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (p0 + i < nnz)
+            owner[n++] = where[p0 + i] / tile;
+    int distinct = 0;
+    for (int i = 0; i < n; ++i) {
+        bool seen = false;
+        for (int j = 0; j < i; ++j)
+            seen = seen || owner[j] == owner[i];
+        distinct += seen ? 0 : 1;
+    }
+    line_flag[line] = distinct >= min_tiles ? 1 : 0;
+}
+
+// sort key of stream entry e: (tile, cached?, TJDS position) -- a tile's in-place entries first, in TJDS order, then
+// its cached ones
+__global__ __launch_bounds__(256) void window_keys(const int *__restrict__ pos, int nnz, int tile,
+                                                   const unsigned char *__restrict__ line_flag, u64 *__restrict__ key,
+                                                   unsigned *__restrict__ slot, int *__restrict__ cached_count)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= nnz)
         return;
-    key[e] = ((u64)(unsigned)(e / tile) << 32) | (unsigned)pos[e];
+    const unsigned p = (unsigned)pos[e];
+    const unsigned cached = line_flag ? line_flag[p >> 4] : 0u;
+    key[e] = ((u64)(unsigned)(e / tile) << 33) | ((u64)cached << 32) | p;
     slot[e] = (unsigned)(e % tile);
+    if (cached)
+        atomicAdd(&cached_count[e / tile], 1);
 }
 
 __device__ __forceinline__ int diagonal_of(const int *__restrict__ start_pos, int num_diag, int p)
@@ -320,16 +362,31 @@ __device__ __forceinline__ int diagonal_of(const int *__restrict__ start_pos, in
     return lo;
 }
 
+// in-place entry: (TJDS position, slot | diagonal << slot_bits); cached entry: (permuted column, slot) -- diagonal 0, so
+// that the kernel's "position - start_pos[diagonal]" is the column for both -- and its value into the tile's cache
 __global__ __launch_bounds__(256) void window_streams(const u64 *__restrict__ key, const unsigned *__restrict__ slot, int nnz,
-                                                      const int *__restrict__ start_pos, int num_diag, int slot_bits,
-                                                      int *__restrict__ pos_sorted, int *__restrict__ meta)
+                                                      int tile, const int *__restrict__ start_pos, int num_diag, int slot_bits,
+                                                      const int *__restrict__ cache_ptr, const double *__restrict__ val,
+                                                      int *__restrict__ pos_sorted, int *__restrict__ meta,
+                                                      double *__restrict__ val_cache)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= nnz)
         return;
     const int p = (int)(unsigned)(key[e] & 0xffffffffu);
-    pos_sorted[e] = p;
-    meta[e] = (int)(slot[e] | ((unsigned)diagonal_of(start_pos, num_diag, p) << slot_bits));
+    const int d = diagonal_of(start_pos, num_diag, p);
+    if ((key[e] >> 32) & 1u) {
+        const int b = e / tile;
+        const long long tile_end = (long long)(b + 1) * tile < nnz ? (long long)(b + 1) * tile : nnz;
+        const int c0 = cache_ptr[b], c1 = cache_ptr[b + 1];
+        const int first_cached = (int)(tile_end - (c1 - c0));  // stream place of the tile's first cached entry
+        pos_sorted[e] = p - start_pos[d];
+        meta[e] = (int)slot[e];
+        val_cache[c0 + (e - first_cached)] = val[p];
+    } else {
+        pos_sorted[e] = p;
+        meta[e] = (int)(slot[e] | ((unsigned)d << slot_bits));
+    }
 }
 
 __global__ __launch_bounds__(256) void overflow_entries(const int *__restrict__ pos, const int *__restrict__ ovf_ptr,
@@ -359,30 +416,69 @@ namespace smvp {
 
 // kFlavorTjdsS: the row-major stream `d_pos` cut into windows of `tile` entries, every window sorted by TJDS position;
 // meta = the entry's place in its window before sorting (its LDS slot) | its jagged diagonal << slot_bits.
+// cache_min_tiles > 0: entries of val lines that scatter over that many tiles or more (mark_scattered_lines) come last
+// in their window and carry (permuted column, slot); their values are copied, window by window, into *d_val_cache
+// (allocated here, hipFree by the caller), d_cache_ptr[ntiles + 1] = where each window's run starts.  0: no cache
+// (d_cache_ptr all zero, *d_val_cache a dummy).
 int sort_tile_windows(const int *d_pos, int nnz, int tile, const int *d_start_pos, int num_diag, int slot_bits,
-                      int *d_pos_sorted, int *d_meta, hipStream_t st)
+                      const double *d_val, int cache_min_tiles, int *d_pos_sorted, int *d_meta, int *d_cache_ptr,
+                      double **d_val_cache, int *cached_total, hipStream_t st)
 {
-    if (nnz <= 0)
+    const int ntiles = std::max(1, (int)(((long long)nnz + tile - 1) / tile));
+    *d_val_cache = nullptr;
+    *cached_total = 0;
+    HIP_TRY(hipMemsetAsync(d_cache_ptr, 0, sizeof(int) * ((size_t)ntiles + 1), st));
+    if (nnz <= 0) {
+        HIP_TRY(hipMalloc((void **)d_val_cache, 4 * sizeof(double)));
+        HIP_TRY(hipStreamSynchronize(st));
         return SMVP_OK;
+    }
     if (tile > (1 << slot_bits) || ((long long)(num_diag - 1) >> (32 - slot_bits)) != 0)
         return smvp::fail(SMVP_ERR_UNSUPPORTED, "sort_tile_windows: tile %d / %d diagonals do not fit the packed word", tile, num_diag);
     Scratch sc;
     u64 *k0, *k1;
     unsigned *s0, *s1;
+    int *count;
+    unsigned char *flag = nullptr;
     HIP_TRY(sc.get(&k0, (size_t)nnz));
     HIP_TRY(sc.get(&k1, (size_t)nnz));
     HIP_TRY(sc.get(&s0, (size_t)nnz));
     HIP_TRY(sc.get(&s1, (size_t)nnz));
-    hipLaunchKernelGGL(window_keys, dim3(blocks_for(nnz)), dim3(256), 0, st, d_pos, nnz, tile, k0, s0);
+    HIP_TRY(sc.get(&count, (size_t)ntiles + 1));
+    HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * ((size_t)ntiles + 1), st));
+    if (cache_min_tiles > 0) {
+        int *where;
+        const int nlines = (nnz + 15) / 16;
+        HIP_TRY(sc.get(&where, (size_t)nnz));
+        HIP_TRY(sc.get(&flag, (size_t)nlines));
+        hipLaunchKernelGGL(invert_positions, dim3(blocks_for(nnz)), dim3(256), 0, st, d_pos, nnz, where);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(mark_scattered_lines, dim3(blocks_for(nlines)), dim3(256), 0, st, where, nnz, tile, cache_min_tiles, flag);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(window_keys, dim3(blocks_for(nnz)), dim3(256), 0, st, d_pos, nnz, tile, flag, k0, s0, count);
     HIP_TRY(hipGetLastError());
-    const unsigned bits = 32u + (unsigned)bits_for((nnz + tile - 1) / tile + 1);
+    const unsigned bits = 33u + (unsigned)bits_for(ntiles + 1);
     size_t tmp_bytes = 0;
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, s0, s1, (size_t)nnz, 0u, bits, st));
     char *tmp;
     HIP_TRY(sc.get(&tmp, tmp_bytes));
     HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, s0, s1, (size_t)nnz, 0u, bits, st));
-    hipLaunchKernelGGL(window_streams, dim3(blocks_for(nnz)), dim3(256), 0, st, k1, s1, nnz, d_start_pos, num_diag, slot_bits,
-                       d_pos_sorted, d_meta);
+    {
+        size_t scan_bytes = 0;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, count, d_cache_ptr, 0, (size_t)ntiles + 1, rocprim::plus<int>(), st));
+        char *scan_tmp;
+        HIP_TRY(sc.get(&scan_tmp, scan_bytes));
+        HIP_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, count, d_cache_ptr, 0, (size_t)ntiles + 1, rocprim::plus<int>(), st));
+    }
+    int total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, d_cache_ptr + ntiles, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (hipMalloc((void **)d_val_cache, sizeof(double) * (size_t)std::max(total, 4)) != hipSuccess)
+        return smvp::fail(SMVP_ERR_ALLOC, "sort_tile_windows: cannot allocate the value cache (%d entries)", total);
+    *cached_total = total;
+    hipLaunchKernelGGL(window_streams, dim3(blocks_for(nnz)), dim3(256), 0, st, k1, s1, nnz, tile, d_start_pos, num_diag, slot_bits,
+                       d_cache_ptr, d_val, d_pos_sorted, d_meta, *d_val_cache);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     return SMVP_OK;

@@ -122,6 +122,10 @@ struct smvp_csr {
     int num_diag = 0;
     // TjdsS: per-tile TJDS-ordered streams and the tiles' overflow entries, owned, rebuilt with the tile plan
     int *d_pos_sorted = nullptr, *d_meta = nullptr, *d_ovf_ptr = nullptr, *d_ovf_pos = nullptr, *d_ovf_k = nullptr;
+    // TjdsS: values of the entries whose val lines scatter over cache_min_tiles tiles or more, kept tile by tile (0: none)
+    int cache_min_tiles = 8, cached_total = 0;
+    int *d_cache_ptr = nullptr;
+    double *d_val_cache = nullptr;
     int kernel = SMVP_CSR_KERNEL_AUTO;  // resolved: never AUTO once a plan exists
     int lanes_per_row = 64;             // VECTOR
     int vpt = 4;                        // STREAM: entries per thread (tile = 256 * vpt)
@@ -257,10 +261,13 @@ void free_stream_plan(smvp_csr *h)
         (void)hipFree(h->d_carry);
     if (h->d_tile_next)
         (void)hipFree(h->d_tile_next);
-    for (void *p : {(void *)h->d_pos_sorted, (void *)h->d_meta, (void *)h->d_ovf_ptr, (void *)h->d_ovf_pos, (void *)h->d_ovf_k})
+    for (void *p : {(void *)h->d_pos_sorted, (void *)h->d_meta, (void *)h->d_ovf_ptr, (void *)h->d_ovf_pos, (void *)h->d_ovf_k,
+                    (void *)h->d_cache_ptr, (void *)h->d_val_cache})
         if (p)
             (void)hipFree(p);
-    h->d_pos_sorted = h->d_meta = h->d_ovf_ptr = h->d_ovf_pos = h->d_ovf_k = nullptr;
+    h->d_pos_sorted = h->d_meta = h->d_ovf_ptr = h->d_ovf_pos = h->d_ovf_k = h->d_cache_ptr = nullptr;
+    h->d_val_cache = nullptr;
+    h->cached_total = 0;
     h->d_tile_row = h->d_carry_row = h->d_tile_next = nullptr;
     h->d_carry = nullptr;
     h->ntiles = 0;
@@ -316,10 +323,12 @@ int build_stream_plan(smvp_csr *h)
         if (hipMalloc((void **)&h->d_pos_sorted, n * sizeof(int)) != hipSuccess ||
             hipMalloc((void **)&h->d_meta, n * sizeof(int)) != hipSuccess ||
             hipMalloc((void **)&h->d_ovf_pos, m * sizeof(int)) != hipSuccess ||
-            hipMalloc((void **)&h->d_ovf_k, m * sizeof(int)) != hipSuccess)
+            hipMalloc((void **)&h->d_ovf_k, m * sizeof(int)) != hipSuccess ||
+            hipMalloc((void **)&h->d_cache_ptr, ((size_t)ntiles + 2) * sizeof(int)) != hipSuccess)
             return smvp::fail(SMVP_ERR_ALLOC, "cannot allocate the tile-ordered TJDS streams");
-        if (int rc = smvp::sort_tile_windows(h->d_pos, h->nnz, tile, h->d_start_pos, h->num_diag, smvp::kSlotBits,
-                                             h->d_pos_sorted, h->d_meta, nullptr))
+        if (int rc = smvp::sort_tile_windows(h->d_pos, h->nnz, tile, h->d_start_pos, h->num_diag, smvp::kSlotBits, h->d_val,
+                                             h->cache_min_tiles, h->d_pos_sorted, h->d_meta, h->d_cache_ptr, &h->d_val_cache,
+                                             &h->cached_total, nullptr))
             return rc;
         if (int rc = smvp::build_tile_overflow(h->d_pos, h->d_ovf_ptr, total, ntiles, tile, h->nnz, h->d_start_pos,
                                                h->num_diag, h->d_ovf_pos, h->d_ovf_k, nullptr))
@@ -408,6 +417,8 @@ static int csr_create_impl(smvp_csr_t **out, int device, int rows, int cols, int
     if (src) {
         h->d_pos = src->pos, h->d_start_pos = src->start_pos;
         h->num_diag = src->num_diag;
+        if (const char *e = getenv("SMVP_TJDS_CACHE"))  // development switch: 0 = no value cache, else tiles per val line
+            h->cache_min_tiles = std::min(16, std::max(0, atoi(e)));
     }
     h->rows = rows, h->cols = cols, h->nnz = nnz;
     h->h_row_ptr.resize((size_t)rows + 1);
@@ -547,6 +558,7 @@ static int csr_spmv_impl(smvp_csr_t *h, const double *d_x, double *d_y, void *st
         if (h->flavor == smvp::kFlavorTjdsS) {
             l.pos = h->d_pos_sorted, l.col_ind = h->d_meta;
             l.ovf_ptr = h->d_ovf_ptr, l.ovf_pos = h->d_ovf_pos, l.ovf_k = h->d_ovf_k;
+            l.cache_ptr = h->d_cache_ptr, l.val_cache = h->d_val_cache;
         }
         l.stamps = stamps;
         l.rows = h->rows, l.nnz = h->nnz, l.ntiles = h->ntiles;
@@ -949,6 +961,32 @@ extern "C" int smvp_tjds_describe(const smvp_tjds_t *h, char *kernel_name, size_
     }
     if (alg_bytes)
         *alg_bytes = 12.0 * h->planned_nnz + 4.0 * (h->num_diag + 1.0) + 8.0 * h->cols + 8.0 * h->rows;
+    return SMVP_OK;
+}
+
+// Which values the one-kernel product keeps a second copy of: those of val lines whose 16 entries belong to
+// `min_tiles` tiles or more (0: none -- every value is read from val itself).  Rebuilds the plan.
+extern "C" int smvp_tjds_set_value_cache(smvp_tjds_t *h, int min_tiles)
+{
+    if (!h || !h->rg || min_tiles < 0 || min_tiles > 16)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_set_value_cache: needs the row-gather plan and 0 <= min_tiles <= 16");
+    if (h->rg->flavor != smvp::kFlavorTjdsS)
+        return min_tiles == 0 ? (int)SMVP_OK
+                              : smvp::fail(SMVP_ERR_UNSUPPORTED, "the value cache belongs to the tile-ordered TJDS stream");
+    DeviceScope on(h->device);
+    h->rg->cache_min_tiles = min_tiles;
+    return build_stream_plan(h->rg);
+}
+
+extern "C" int smvp_tjds_get_value_cache(const smvp_tjds_t *h, int *min_tiles, long long *cached_entries)
+{
+    if (!h)
+        return smvp::fail(SMVP_ERR_INVALID, "null handle");
+    const bool on = h->rg && h->rg->flavor == smvp::kFlavorTjdsS;
+    if (min_tiles)
+        *min_tiles = on ? h->rg->cache_min_tiles : 0;
+    if (cached_entries)
+        *cached_entries = on ? h->rg->cached_total : 0;
     return SMVP_OK;
 }
 

@@ -40,6 +40,8 @@ struct OwnerLaunch {
     const int *start_pos = nullptr;
     unsigned long long *stamps = nullptr;  // owner_stamp_slots(ntiles) pairs, or nullptr
     const int *ovf_ptr = nullptr, *ovf_pos = nullptr, *ovf_k = nullptr;  // kFlavorTjdsS
+    const int *cache_ptr = nullptr;                                      // kFlavorTjdsS
+    const double *val_cache = nullptr;
     int rows = 0, nnz = 0, ntiles = 0;
 };
 hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hipStream_t stream);

@@ -219,6 +219,8 @@ struct OwnerExtra {
     const int *ovf_ptr;             // TjdsS: ntiles + 1 bounds of the tiles' overflow entries in ovf_pos / ovf_k
     const int *ovf_pos;             // TjdsS: TJDS position ...
     const int *ovf_k;               // TjdsS: ... and permuted column of the entries [e, tile_next) of each tile, row order
+    const int *cache_ptr;           // TjdsS: ntiles + 1 bounds of the tiles' runs in val_cache (a tile's last entries)
+    const double *val_cache;        // TjdsS: values of the entries whose val lines scatter over many tiles, tile by tile
     unsigned long long *stamps;     // STAMPED: per-wave {first, last} wall-clock ticks of this launch
     int stream_nt;                  // TjdsS: load the pos / slot streams non-temporally (development switch)
 };
@@ -372,9 +374,12 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     double p[VPT];
     double po = 0.0;
     int rp_a = 0, rp_b = 0;
-    int ovf_base = 0;
-    if constexpr (SORTED)
+    int ovf_base = 0, cache0 = 0, in_place = 0;
+    if constexpr (SORTED) {
         ovf_base = ex.ovf_ptr[b];
+        cache0 = ex.cache_ptr[b];
+        in_place = (e - lo) - (ex.cache_ptr[b + 1] - cache0);  // entries of this tile whose value is read from val itself
+    }
     if constexpr (SORTED) {
         if (full_tile && rlo + t < rhi) {
             rp_a = row_ptr[rlo + t];
@@ -393,9 +398,14 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
                 c[k] = pj[k] - a.start_pos[(unsigned)c[k] >> kSlotBits];
             }
             double xk[VPT];
+            // the tile's last `cached` entries take their value from the tile's own run of the cache (coalesced) instead
+            // of val[position]: their val lines are shared with many other tiles (see mark_scattered_lines)
 #pragma unroll
-            for (int k = 0; k < VPT; ++k)
-                v[k] = a.val[pj[k]];
+            for (int k = 0; k < VPT; ++k) {
+                const int idx = k * kStreamBlock + t;
+                const double *src = idx < in_place ? a.val + pj[k] : ex.val_cache + (cache0 + (idx - in_place));
+                v[k] = *src;
+            }
             const double vo = over0 ? a.val[pjo] : 0.0;
 #pragma unroll
             for (int k = 0; k < VPT; ++k)
@@ -407,9 +417,12 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
             po = vo * xo;
         } else {  // the last, partial tile
             for (int k = 0; k < VPT; ++k) {
-                const long long j = s + k * kStreamBlock + t;
-                if (j < (long long)nnz)
-                    prod[a.col_ind[j] & ((1 << kSlotBits) - 1)] = owner_product_slow<FLAVOR>(a, j);
+                const int idx = k * kStreamBlock + t;
+                if (s + idx < (long long)nnz) {
+                    const int pw = a.pos[s + idx], m = a.col_ind[s + idx];
+                    const double vv = idx < in_place ? a.val[pw] : ex.val_cache[cache0 + (idx - in_place)];
+                    prod[m & ((1 << kSlotBits) - 1)] = vv * a.x[pw - a.start_pos[(unsigned)m >> kSlotBits]];
+                }
             }
             if (over0)
                 po = a.val[pjo] * a.x[co];
@@ -822,6 +835,7 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
     }();
     OwnerExtra ex;
     ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_pos = l.ovf_pos, ex.ovf_k = l.ovf_k;
+    ex.cache_ptr = l.cache_ptr, ex.val_cache = l.val_cache;
     ex.stamps = l.stamps, ex.stream_nt = nt;
 #define SMVP_OWNER_ST(V, F, S)                                                                                     \
     hipLaunchKernelGGL((csr_stream_owner<V, F, S>), grid, dim3(kStreamBlock), 0, stream, l.row_ptr, l.col_ind, l.val, \

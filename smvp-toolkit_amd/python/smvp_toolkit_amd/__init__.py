@@ -70,7 +70,7 @@ EXPORTS = [
     "smvp_csr_create", "smvp_csr_set_kernel", "smvp_csr_get_kernel", "smvp_csr_gather_spread", "smvp_csr_spmv",
     "smvp_csr_describe", "smvp_csr_plan_launches", "smvp_csr_destroy",
     "smvp_tjds_create", "smvp_tjds_set_x", "smvp_tjds_zero_y", "smvp_tjds_spmv",
-    "smvp_tjds_set_ref_quirks", "smvp_tjds_set_mode", "smvp_tjds_set_tile", "smvp_tjds_describe", "smvp_tjds_destroy",
+    "smvp_tjds_set_ref_quirks", "smvp_tjds_set_mode", "smvp_tjds_set_tile", "smvp_tjds_set_value_cache", "smvp_tjds_get_value_cache", "smvp_tjds_describe", "smvp_tjds_destroy",
     "smvp_shard_opts_default", "smvp_csr_sharded_create", "smvp_csr_sharded_create_ex", "smvp_tjds_sharded_create",
     "smvp_tjds_sharded_create_ex", "smvp_sharded_layout", "smvp_sharded_set_csr_kernel", "smvp_sharded_set_x", "smvp_sharded_spmv",
     "smvp_sharded_synchronize", "smvp_sharded_feed_back", "smvp_sharded_get_y", "smvp_sharded_info", "smvp_sharded_destroy",
@@ -107,6 +107,8 @@ def lib():
         L.smvp_tjds_set_ref_quirks.argtypes = [vp, ci, ci, ci]
         L.smvp_tjds_set_mode.argtypes = [vp, ci]
         L.smvp_tjds_set_tile.argtypes = [vp, ci]
+        L.smvp_tjds_set_value_cache.argtypes = [vp, ci]
+        L.smvp_tjds_get_value_cache.argtypes = [vp, C.POINTER(ci), C.POINTER(C.c_longlong)]
         L.smvp_last_run_info.argtypes = [C.POINTER(RunInfo)]
         L.smvp_tjds_describe.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double)]
         L.smvp_tjds_destroy.argtypes = [vp]
@@ -471,6 +473,16 @@ class TjdsMatrix:
 
     def set_tile(self, entries_per_tile):
         _check(lib().smvp_tjds_set_tile(self._h, entries_per_tile), "smvp_tjds_set_tile")
+
+    def set_value_cache(self, min_tiles):
+        """Keep a second copy of the values of val lines shared by `min_tiles` tiles or more (0 = none)."""
+        _check(lib().smvp_tjds_set_value_cache(self._h, int(min_tiles)), "smvp_tjds_set_value_cache")
+
+    def get_value_cache(self):
+        """(min_tiles, cached entries)."""
+        m, n = C.c_int(), C.c_longlong()
+        _check(lib().smvp_tjds_get_value_cache(self._h, C.byref(m), C.byref(n)), "smvp_tjds_get_value_cache")
+        return m.value, n.value
 
     def set_ref_quirks(self, enable=True):
         _check(lib().smvp_tjds_set_ref_quirks(self._h, int(enable), self._t.ref_num_tjdiag,

@@ -2,7 +2,8 @@
 """Time the TJDS product forms (and the CSR product beside them) on HBM-sized workloads; check each against CSR.
 
     python3 tools/exp_tjds.py --workloads memplus_tiled,pwt_tiled,random,uniform --steps 20
-Variants: mode[:index[:tile]]  with mode in two_phase | atomic | gather, index in sorted | k32, tile 256|1024|2048.
+Variants: mode[:index[:tile[:cache]]]  with mode in two_phase | atomic | gather, index in sorted | k32, tile 256|1024|2048
+(0 = default), cache = tiles per val line from which on the values are cached (0 = none; default 8).
 """
 import argparse, os, sys, time
 import numpy as np
@@ -96,8 +97,10 @@ def main():
             t0 = time.perf_counter()
             T = sm.TjdsMatrix(tj)          # default plan is built here ...
             T.set_mode(mode)               # ... and the variant's own one here
-            if len(parts) > 2 and mode >= sm.TJDS_MODE_ROW_GATHER:
+            if len(parts) > 2 and int(parts[2]) and mode >= sm.TJDS_MODE_ROW_GATHER:
                 T.set_tile(int(parts[2]))
+            if len(parts) > 3 and mode >= sm.TJDS_MODE_ROW_GATHER:
+                T.set_value_cache(int(parts[3]))
             torch.cuda.synchronize()
             plan_s = time.perf_counter() - t0
             T.set_x(x, stream=st)
@@ -112,8 +115,9 @@ def main():
             err = float(((y - y_csr).abs() / scale.clamp_min(1e-300)).max())
             tname, tbytes = T.describe()
             ms, mn = timeit(torch, step, a.steps)
-            print("%-44s %8.4f ms (min %.4f)  %5.1f %% of 8 TB/s  %7.1f GFLOP/s  err %.1e  plan %.2f s  [%s]" % (
-                var, ms, mn, tbytes / ms * 1e-6 / 80.0, 2 * nnz / ms * 1e-6, err, plan_s, tname), flush=True)
+            cache = T.get_value_cache()
+            print("%-44s %8.4f ms (min %.4f)  %5.1f %% of 8 TB/s  %7.1f GFLOP/s  err %.1e  plan %.2f s  [%s] cache >= %d tiles: %.1f %% of the values" % (
+                var, ms, mn, tbytes / ms * 1e-6 / 80.0, 2 * nnz / ms * 1e-6, err, plan_s, tname, cache[0], 100.0 * cache[1] / max(nnz, 1)), flush=True)
             T.close()
             del T
         del tj, y, y_csr, scale, x
