@@ -122,8 +122,11 @@ struct smvp_csr {
     int num_diag = 0;
     // TjdsS: per-tile TJDS-ordered streams and the tiles' overflow entries, owned, rebuilt with the tile plan
     int *d_pos_sorted = nullptr, *d_meta = nullptr, *d_ovf_ptr = nullptr, *d_ovf_pos = nullptr, *d_ovf_k = nullptr;
-    // TjdsS: values of the entries whose val lines scatter over cache_min_tiles tiles or more, kept tile by tile (0: none)
-    int cache_min_tiles = 8, cached_total = 0;
+    // TjdsS: values of the entries whose val lines scatter over cache_min_tiles tiles or more, kept tile by tile (0: none).
+    // A line split over two or three tiles is the edge between neighbouring tiles (they run together on one XCD: an L2
+    // hit); from four on its entries belong to unrelated rows.  Measured on memplus x944 (profiles/r03_tjds_forms_measured.txt):
+    // none 0.555 ms / 3.66 GB moved, >= 8 tiles 0.461 / 2.92 (20 % of the values cached), >= 4 tiles 0.444 / 2.73 (35 %).
+    int cache_min_tiles = 4, cached_total = 0;
     int *d_cache_ptr = nullptr;
     double *d_val_cache = nullptr;
     int kernel = SMVP_CSR_KERNEL_AUTO;  // resolved: never AUTO once a plan exists

@@ -232,6 +232,7 @@ TJDS_MODES = [sm.TJDS_MODE_ROW_GATHER, sm.TJDS_MODE_TWO_PHASE, sm.TJDS_MODE_ATOM
 # the one-kernel product: (index form of its stream, entries per tile); "sorted" = every tile in TJDS order (default)
 TJDS_GATHER_VARIANTS = [("sorted", 0), ("sorted", 256), ("sorted", 1024), ("sorted", 2048), ("k32", 256), ("k32", 1024),
                         ("k32", 2048)]
+TJDS_FLAVORS = {"sorted": (3,), "k32": (2,)}
 
 
 def tjds_gather_matrix(t, index, tile):
@@ -247,12 +248,37 @@ def tjds_gather_matrix(t, index, tile):
             os.environ["SMVP_TJDS_INDEX"] = old
     if tile:
         T.set_tile(tile)
-    flavor = 3 if index == "sorted" else 2
     name = T.describe()[0]
-    assert name.endswith(", %d, false>" % flavor), name
+    assert any(name.endswith(", %d, false>" % f) for f in TJDS_FLAVORS[index]), name
     if tile:
-        assert name == "csr_stream_owner<%d, %d, false>" % (tile // 256, flavor), name
+        assert any(name == "csr_stream_owner<%d, %d, false>" % (tile // 256, f) for f in TJDS_FLAVORS[index]), name
     return T
+
+
+def test_tjds_value_cache_and_run_words_do_not_change_a_bit(torch):
+    """The one-kernel product sums every row in ascending TJDS position whatever the plan keeps: values read from val or
+    from the tiles' cache (lines shared by >= 1, 2, 8, 16 tiles, or none), any tile size -- the same bits every time."""
+    for name in ("memplus.mtx", "pwt.mtx"):
+        m, n, coo = load(name)
+        t = sm.tjds_from_coo(coo, m, n)
+        x = dev(torch, np.random.default_rng(3).random(n))
+        want = None
+        for index in ("sorted",):
+            for tile in (256, 2048):
+                T = tjds_gather_matrix(t, index, tile)
+                T.set_x(x)
+                for cache in (0, 1, 2, 8, 16):
+                    T.set_value_cache(cache)
+                    got_min, cached = T.get_value_cache()
+                    assert got_min == cache and (cached == 0) == (cache == 0) or cache > 8
+                    if cache == 1:
+                        assert cached == len(coo)
+                    dy = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+                    T.spmv(dy)
+                    torch.cuda.synchronize()
+                    want = dy.clone() if want is None else want
+                    assert torch.equal(dy, want), (name, index, tile, cache)
+                T.close()
 
 
 @pytest.mark.parametrize("name", SAMPLES)
