@@ -372,6 +372,9 @@ int smvp_synth_fill(int kind, uint64_t seed, int64_t rows_total, int64_t cols_to
                     int *col_ind, double *val, int threads);
 /* Row-block partition balanced by nnz: bounds[parts+1], bounds[0]=0, bounds[parts]=rows. */
 int smvp_partition_rows(const int *row_ptr, int rows, int parts, int *bounds);
+/* x[i] uniform in [0, 1): the top 53 bits of splitmix64's finaliser of (seed + i), times 2^-53.  The operand of the
+ * command line's --x random (seed 67890); the reference only ever multiplies by ones (main-cli.c:368-369). */
+int smvp_vector_random(double *x, int64_t n, uint64_t seed);
 
 #ifdef __cplusplus
 }

@@ -21,8 +21,9 @@
  *     same POSIX ordering rule.
  * Additive flags: --device N, --gpus N, --iterate, --normalize, --ref-quirks, --device-convert, --csr-kernel auto|vector|stream|stream-carry|colsweep,
  * --tjds-mode auto|row-gather|two-phase|atomic, --timing auto|events|device, --expand-symmetric, --cache,
- * --quiet-arrays is implied (the reference's SMVP_CSR_DEBUG array dumps,
- * main-cli.c:374-394, are not printed).
+ * --x ones|random, --dump-arrays.  The reference's shipped binary prints whole arrays (SMVP_CSR_DEBUG 1,
+ * main-cli.c:10,374-394,458-466,1166-1191); here those dumps -- and the TJDS ones its source holds behind
+ * SMVP_TJDS_DEBUG (main-cli.c:870-892,969-992,1150-1158) -- are printed only with --dump-arrays.
  */
 #define _POSIX_C_SOURCE 200809L
 #include "smvp_amd.h"
@@ -44,7 +45,7 @@
 
 enum { ALG_NONE = 0, ALG_CSR = 1 << 1, ALG_TJDS = 1 << 2, ALG_CISR = 1 << 3, ALG_ALL = 256 };
 enum { OPT_DEVICE = 1000, OPT_QUIRKS, OPT_KERNEL, OPT_USAGE, OPT_DEVCONV, OPT_GPUS, OPT_ITERATE, OPT_NORMALIZE, OPT_TIMING,
-       OPT_TJDS_MODE, OPT_EXPAND, OPT_CACHE };
+       OPT_TJDS_MODE, OPT_EXPAND, OPT_CACHE, OPT_X, OPT_DUMP };
 
 static void usage(FILE *to, const char *prog)
 {
@@ -53,7 +54,7 @@ static void usage(FILE *to, const char *prog)
             "        [-n|--number=1000] [-s|--slots=16] [-d|--dir=./] [--device=0] [--gpus=1]\n"
             "        [--ref-quirks] [--iterate] [--normalize] [--device-convert] [--csr-kernel=auto|vector|stream|stream-carry|colsweep]\n"
             "        [--tjds-mode=auto|row-gather|two-phase|atomic] [--timing=auto|events|device]\n"
-            "        [--expand-symmetric] [--cache]\n"
+            "        [--expand-symmetric] [--cache] [--x=ones|random] [--dump-arrays]\n"
             "        [-?|--help] [--usage]\n"
             "        [OPTIONS] <file>\n",
             prog);
@@ -81,6 +82,9 @@ static void help(const char *prog)
     puts("      --timing=auto        Per-product window: events (hipEvent pair), device (the kernel times itself), auto.");
     puts("      --expand-symmetric   Mirror the stored triangle of a symmetric file (the reference multiplies it as stored).");
     puts("      --cache              Keep / use <file>.smvpbin, a binary copy of the loaded matrix tied to the file's checksum.");
+    puts("      --x=ones             Operand: ones (the reference's) or random (uniform [0, 1), seed 67890).");
+    puts("      --dump-arrays        Print the converted arrays, the result vector and every product's time like the");
+    puts("                           reference's debug build (its shipped binary always does, for CSR).");
     puts("\nHelp options:");
     puts("  -?, --help               Show this help message");
     puts("      --usage              Display brief usage message");
@@ -130,7 +134,7 @@ static void engine_fail(const char *what, int rc)
     exit(1);
 }
 
-static void print_rates(const char *alg, int rows, int cols, int nnz, int diags, const smvp_time_stats_t *t)
+static void print_rates(const char *alg, int rows, int cols, int nnz, int diags, int iters, const smvp_time_stats_t *t)
 {
     /* 2*nnz flops; 12*nnz + 4*(rows+1 | diags+1) + 8*cols + 8*rows bytes */
     const double flops = 2.0 * nnz;
@@ -138,15 +142,128 @@ static void print_rates(const char *alg, int rows, int cols, int nnz, int diags,
     if (t->time_avg > 0.0)
         printf(CYAN "[DATA]\t%s average per product: " RESET "%g ms, %.3f GFLOP/s, %.3f GB/s algorithmic\n", alg,
                t->time_avg, flops / t->time_avg * 1e-6, bytes / t->time_avg * 1e-6);
-    /* how the window of main-cli.c:408-419 was taken, and what the whole loop cost the host */
+    /* How the window of main-cli.c:408-419 was taken.  The reference's clock brackets the product call on the host; here
+     * three figures exist and all are printed: the in-kernel window (what the report file's times are when the kernel
+     * times itself: launch and dispatch excluded), the host wall of the whole loop per product (capture, replays and
+     * read-back included), and -- with --timing events -- a hipEvent pair around every launch (which for launches of a
+     * few microseconds measures mostly the events).  rocprofv3 reads 4.8 us per dispatch for the sample matrices'
+     * kernels inside the graph replay (profiles/r03_cli_n1000.txt). */
     smvp_run_info_t info;
-    if (smvp_last_run_info(&info) == SMVP_OK && info.wall_ms > 0.0)
+    if (smvp_last_run_info(&info) == SMVP_OK && info.wall_ms > 0.0) {
         printf(CYAN "[DATA]\t%s timing: " RESET "%s; whole loop %g ms of host wall time\n", alg,
                info.timing == SMVP_TIMING_DEVICE
                    ? (info.graph_replays ? "per product on the device (wall-clock stamps in the kernel), products replayed from a hipGraph"
                                          : "per product on the device (wall-clock stamps in the kernel)")
                    : "hipEvent pair around each product",
                info.wall_ms);
+        printf(CYAN "[DATA]\t%s per product: " RESET "%.3f us %s (the times in the report file), %.3f us host wall per product over the loop\n",
+               alg, t->time_avg * 1e3,
+               info.timing == SMVP_TIMING_DEVICE ? "in-kernel window, launch excluded" : "between the events of a pair",
+               iters > 0 ? info.wall_ms * 1e3 / iters : 0.0);
+    }
+}
+
+/* ---- --dump-arrays: the reference's debug dumps, text for text ---------------------------------------------------- */
+static void dump_ints(const char *head, const int *a, int n)
+{
+    fputs(head, stdout);
+    for (int i = 0; i < n; ++i)
+        printf("%d, ", a[i]);
+}
+
+static void dump_vector(const char *head, const double *v, int n)
+{
+    fputs(head, stdout);
+    for (int i = 0; i < n; ++i)
+        printf("%g, ", v[i]);
+    printf("]\n\n");
+}
+
+/* main-cli.c:374-394 (SMVP_CSR_DEBUG): row_ptr, val, col_ind as smvp_csr_compute converts them */
+static void dump_csr_arrays(const smvp_coo_t *coo, int rows, int nnz)
+{
+    int *rp = malloc(sizeof *rp * ((size_t)rows + 1)), *ci = malloc(sizeof *ci * (size_t)(nnz > 0 ? nnz : 1));
+    double *v = malloc(sizeof *v * (size_t)(nnz > 0 ? nnz : 1));
+    if (!rp || !ci || !v)
+        die("Out of memory while staging the matrix.");
+    const int rc = smvp_csr_from_coo(coo, rows, nnz, rp, ci, v);
+    if (rc != SMVP_OK)
+        engine_fail("Converting to CSR", rc);
+    dump_ints("[DEBUG]\tCSR JIT row_ptr:\n\t[", rp, rows + 1);
+    printf("]\n");
+    printf("[DEBUG]\tCSR JIT val:\n\t[");
+    for (int i = 0; i < nnz; ++i)
+        printf("%g, ", v[i]);
+    printf("]\n");
+    dump_ints("[DEBUG]\tCSR JIT col_ind:\n\t[", ci, nnz);
+    printf("]\n\n");
+    free(rp);
+    free(ci);
+    free(v);
+}
+
+/* smvp_csr_debug, main-cli.c:1166-1191 (its "StDev Time" line prints the average: kept as it is) */
+static void dump_csr_run(const double *y, const double *each, const smvp_time_stats_t *t, int rows, int nnz, int iters)
+{
+    printf("[DEBUG]\tCSR Iterations: %d\n", iters);
+    printf("[DEBUG]\tCSR fInputRows: %d\n", rows);
+    printf("[DEBUG]\tCSR fInputNonZeros: %d\n", nnz);
+    printf("[DEBUG]\tCSR Total Time: %g\n", t->time_total);
+    printf("[DEBUG]\tCSR Avg Time: %g\n", t->time_avg);
+    printf("[DEBUG]\tCSR StDev Time: %g\n", t->time_avg);
+    printf("[DEBUG]\tCSR Times:\n");
+    printf("\t[");
+    for (int i = 0; i < iters; ++i)
+        printf("%g, ", each[i]);
+    printf("]\n");
+    dump_vector("[DEBUG]\tCSR Output Vector:\n\t[", y, rows);
+}
+
+/* main-cli.c:870-892 (the reordering table) and :969-992 (val, row_ind, start_pos, num_tjdiag).  start_pos is printed
+ * with its terminator over all jagged diagonals; with --ref-quirks over the reference's own count (the length of
+ * original column 0, main-cli.c:865) as its loop at :985 does. */
+static void dump_tjds_arrays(const smvp_coo_t *coo, int rows, int cols, int nnz, int quirks)
+{
+    const size_t cap = (size_t)(rows > nnz ? rows : nnz) + 2;
+    int *perm = malloc(sizeof *perm * (size_t)(cols > 0 ? cols : 1)), *sp = malloc(sizeof *sp * cap);
+    int *ri = malloc(sizeof *ri * (size_t)(nnz > 0 ? nnz : 1)), *len = calloc((size_t)(cols > 0 ? cols : 1), sizeof *len);
+    double *v = malloc(sizeof *v * (size_t)(nnz > 0 ? nnz : 1));
+    if (!perm || !sp || !ri || !len || !v)
+        die("Out of memory while staging the matrix.");
+    int nd = 0, ref_nd = 0, last_single = 0;
+    const int rc = smvp_tjds_from_coo(coo, rows, cols, nnz, perm, sp, (int)cap, ri, v, &nd, &ref_nd, &last_single);
+    if (rc != SMVP_OK)
+        engine_fail("Converting to TJDS", rc);
+    for (int i = 0; i < nnz; ++i)
+        ++len[coo[i].col];
+    printf("[DEBUG]\tTJDS PHASE 3: Reordering Table:\n");
+    printf("key\t[");
+    for (int k = 0; k < cols; ++k)
+        printf("%d, ", k);
+    printf("]\n");
+    dump_ints("origCol\t[", perm, cols);
+    printf("]\n");
+    printf("colLen\t[");
+    for (int k = 0; k < cols; ++k)
+        printf("%d, ", len[perm[k]]);
+    printf("]\n\n");
+    printf("[DEBUG]\tTJDS PHASE 7: Pre-Calc Fields:\n");
+    printf("\tval:\t\t[");
+    for (int i = 0; i < nnz; ++i)
+        printf("%g, ", v[i]);
+    printf("]\n");
+    dump_ints("\trow_ind:\t[", ri, nnz);
+    printf("]\n");
+    const int shown = quirks ? (ref_nd < nd ? ref_nd : nd) : nd;
+    dump_ints("\tstart_pos:\t[", sp, shown + 1);
+    printf("]\n\n");
+    printf("\tnum_tjdiag (count, not 0-index):\t%d", shown);
+    printf("\n\n");
+    free(perm);
+    free(sp);
+    free(ri);
+    free(len);
+    free(v);
 }
 
 int main(int argc, char *argv[])
@@ -162,11 +279,12 @@ int main(int argc, char *argv[])
         {"iterate", no_argument, NULL, OPT_ITERATE}, {"normalize", no_argument, NULL, OPT_NORMALIZE},
         {"timing", required_argument, NULL, OPT_TIMING}, {"tjds-mode", required_argument, NULL, OPT_TJDS_MODE},
         {"expand-symmetric", no_argument, NULL, OPT_EXPAND}, {"cache", no_argument, NULL, OPT_CACHE},
+        {"x", required_argument, NULL, OPT_X}, {"dump-arrays", no_argument, NULL, OPT_DUMP},
         {NULL, 0, NULL, 0}};
     const char *prog = "smvp-toolkit-cli";
     int alg_mode = ALG_NONE, calc_iter = 1000, cisr_slots = 16, device = 0, quirks = 0;
     int csr_kernel = SMVP_CSR_KERNEL_AUTO, device_convert = 0, ngpus = 1, iterate = 0, normalize = 0;
-    int timing = SMVP_TIMING_AUTO, tjds_mode = SMVP_TJDS_MODE_AUTO, expand = 0, use_cache = 0;
+    int timing = SMVP_TIMING_AUTO, tjds_mode = SMVP_TJDS_MODE_AUTO, expand = 0, use_cache = 0, x_random = 0, dump = 0;
     const char *report_dir = "";
 
     if (argc < 2) { /* main-cli.c:1267-1271 */
@@ -278,6 +396,17 @@ int main(int argc, char *argv[])
             break;
         case OPT_CACHE:
             use_cache = 1;
+            break;
+        case OPT_X:
+            if (strcmp(optarg, "ones") == 0)
+                x_random = 0;
+            else if (strcmp(optarg, "random") == 0)
+                x_random = 1;
+            else
+                die("Unknown operand (use ones or random).");
+            break;
+        case OPT_DUMP:
+            dump = 1;
             break;
         case OPT_USAGE:
             usage(stdout, prog);
@@ -404,7 +533,15 @@ int main(int argc, char *argv[])
         die("Out of memory while staging the matrix.");
 
     printf(CYAN "[DATA]\tNon-zero numbers contained in matrix: " RESET "%d\n", nnz);
-    printf(CYAN "[DATA]\tVector operand in use: " RESET "Ones vector with dimensions [%d, %d]\n", rows, 1);
+    double *x_operand = NULL;
+    if (x_random) { /* additive: the reference multiplies by ones only (main-cli.c:368-369) */
+        x_operand = malloc(sizeof *x_operand * (size_t)(cols > 0 ? cols : 1));
+        if (!x_operand || smvp_vector_random(x_operand, cols, 67890) != SMVP_OK)
+            die("Out of memory while staging the matrix.");
+        printf(CYAN "[DATA]\tVector operand in use: " RESET "Random vector (uniform [0, 1), seed 67890) with dimensions [%d, %d]\n", cols, 1);
+    } else {
+        printf(CYAN "[DATA]\tVector operand in use: " RESET "Ones vector with dimensions [%d, %d]\n", rows, 1);
+    }
     if (iterate)
         printf(CYAN "[DATA]\tPower iteration: " RESET "each result is the next operand%s\n",
                normalize ? ", scaled to largest magnitude 1" : "");
@@ -436,34 +573,45 @@ int main(int argc, char *argv[])
     opts.normalize = normalize;
     opts.timing = timing;
     opts.tjds_mode = tjds_mode;
+    opts.x = x_operand;
     smvp_time_stats_t st;
     char path[4096];
 
     if (run_csr) {
         printf(YELLOW "[INFO]\tConverting loaded content to CSR format.\n" RESET);
         printf(YELLOW "[INFO]\tCalculating %d iterations of SMVP CSR.\n" RESET, calc_iter);
+        if (dump)
+            dump_csr_arrays(coo, rows, nnz);
         rc = smvp_csr_compute(coo, rows, cols, nnz, calc_iter, &opts, y, each, &st);
         if (rc != SMVP_OK)
             engine_fail("CSR product", rc);
+        if (dump)
+            dump_vector("[DEBUG]\tCSR JIT Vector Out:\n\t[", y, rows); /* main-cli.c:458-466 */
         rc = smvp_generate_report_text(input, report_dir, "CSR", nnz, rows, calc_iter, y, &st, 0, path, sizeof path);
         if (rc != SMVP_OK)
             engine_fail("Writing the CSR report", rc);
         printf(MAGENTA "[FILE]\tExecution report file saved as:\n" RESET);
         printf("\t%s\n", path);
-        print_rates("CSR", rows, cols, nnz, -1, &st);
+        print_rates("CSR", rows, cols, nnz, -1, calc_iter, &st);
+        if (dump)
+            dump_csr_run(y, each, &st, rows, nnz, calc_iter);
     }
     if (run_tjds) {
         printf(YELLOW "[INFO]\tConverting loaded content to TJDS format.\n" RESET);
+        if (dump)
+            dump_tjds_arrays(coo, rows, cols, nnz, quirks);
         printf(YELLOW "[INFO]\tCalculating %d iterations of SMVP TJDS.\n" RESET, calc_iter);
         rc = smvp_tjds_compute(coo, rows, cols, nnz, calc_iter, &opts, y, each, &st);
         if (rc != SMVP_OK)
             engine_fail("TJDS product", rc);
+        if (dump)
+            dump_vector("[DEBUG]\tTJDS PHASE 8: Output Vector:\n\t[", y, rows); /* main-cli.c:1150-1158 */
         rc = smvp_generate_report_text(input, report_dir, "TJDS", nnz, rows, calc_iter, y, &st, 0, path, sizeof path);
         if (rc != SMVP_OK)
             engine_fail("Writing the TJDS report", rc);
         printf(MAGENTA "[FILE]\tExecution report file saved as:\n" RESET);
         printf("\t%s\n", path);
-        print_rates("TJDS", rows, cols, nnz, 0, &st);
+        print_rates("TJDS", rows, cols, nnz, 0, calc_iter, &st);
     }
 
     if (alg_mode != ALG_ALL && (alg_mode & ALG_CISR)) { /* main-cli.c:1473-1476; host only.  --all-algs = CSR + TJDS */
@@ -480,6 +628,7 @@ int main(int argc, char *argv[])
     free(each);
     free(y);
     free(coo);
+    free(x_operand);
     printf(GREEN "[STOP]\tExit smvp-toolbox v%s\n\n" RESET, smvp_version_string());
     return 0;
 }

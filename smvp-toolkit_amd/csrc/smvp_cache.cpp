@@ -193,8 +193,16 @@ extern "C" int smvp_cache_read_csr(const char *cache_path, int rows, int nnz, in
     p = fnv1a(p, val, sizeof(double) * (size_t)nnz);
     if (p != h.payload_fnv1a)
         return smvp::fail(SMVP_ERR_INVALID, "%s is damaged (payload checksum)", cache_path);
+    // The checksum is no integrity guarantee (a crafted file carries a matching one): what the callers index with --
+    // smvp_coo_from_csr writes out[row_ptr[r] .. row_ptr[r + 1]), the kernels gather x[col_ind[j]] -- is checked itself.
     if (row_ptr[0] != 0 || row_ptr[rows] != nnz)
         return smvp::fail(SMVP_ERR_INVALID, "%s holds an inconsistent row pointer", cache_path);
+    for (int r = 0; r < rows; ++r)
+        if (row_ptr[r] > row_ptr[r + 1])
+            return smvp::fail(SMVP_ERR_INVALID, "%s: row pointer decreases at row %d", cache_path, r);
+    for (int j = 0; j < nnz; ++j)
+        if (col_ind[j] < 0 || col_ind[j] >= h.cols)
+            return smvp::fail(SMVP_ERR_INVALID, "%s: column index %d of entry %d lies outside [0, %d)", cache_path, col_ind[j], j, h.cols);
     return SMVP_OK;
 }
 
@@ -203,6 +211,9 @@ extern "C" int smvp_coo_from_csr(int rows, const int *row_ptr, const int *col_in
 {
     if (rows < 0 || !row_ptr || (row_ptr[rows] > 0 && (!col_ind || !val || !out)))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_coo_from_csr: bad argument");
+    for (int r = 0; r < rows; ++r)  // out[] has row_ptr[rows] entries: nothing may be written outside it
+        if (row_ptr[r] < 0 || row_ptr[r] > row_ptr[r + 1] || row_ptr[r + 1] > row_ptr[rows])
+            return smvp::fail(SMVP_ERR_INVALID, "smvp_coo_from_csr: row_ptr is not a non-decreasing sequence ending at row_ptr[rows]");
     for (int r = 0; r < rows; ++r)
         for (int j = row_ptr[r]; j < row_ptr[r + 1]; ++j) {
             out[j].row = r;

@@ -195,3 +195,14 @@ extern "C" int smvp_synth_fill(int kind, uint64_t seed, int64_t rows_total, int6
         th.join();
     return SMVP_OK;
 }
+
+// x[i] = the top 53 bits of mix64(seed + i) (the splitmix64 finaliser) * 2^-53: uniform in [0, 1), a pure function of
+// (seed, i).  The command line's --x random uses seed 67890; numpy restatement in tests/test_cli_cpu.py.
+extern "C" int smvp_vector_random(double *x, int64_t n, uint64_t seed)
+{
+    if (n < 0 || (n > 0 && !x))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_vector_random: bad argument");
+    for (int64_t i = 0; i < n; ++i)
+        x[i] = (double)(mix64(seed + (uint64_t)i) >> 11) * (1.0 / 9007199254740992.0);
+    return SMVP_OK;
+}

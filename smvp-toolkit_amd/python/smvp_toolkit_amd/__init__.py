@@ -76,7 +76,7 @@ EXPORTS = [
     "smvp_sharded_synchronize", "smvp_sharded_feed_back", "smvp_sharded_get_y", "smvp_sharded_info", "smvp_sharded_destroy",
     "smvp_run_opts_default", "smvp_csr_compute", "smvp_tjds_compute", "smvp_last_run_info",
     "smvp_time_stats", "smvp_generate_report_text", "smvp_cisr_coegen", "smvp_cisr_coegen_path",
-    "smvp_synth_row_lengths", "smvp_synth_fill", "smvp_partition_rows",
+    "smvp_synth_row_lengths", "smvp_synth_fill", "smvp_partition_rows", "smvp_vector_random",
 ]
 
 
@@ -145,6 +145,7 @@ def lib():
         L.smvp_synth_row_lengths.argtypes = [ci, u64, i64, i64, ci, i64, i64, vp]
         L.smvp_synth_fill.argtypes = [ci, u64, i64, i64, ci, i64, i64, vp, vp, vp, ci]
         L.smvp_partition_rows.argtypes = [vp, ci, ci, vp]
+        L.smvp_vector_random.argtypes = [vp, C.c_int64, C.c_uint64]
         L.smvp_mm_read_header_path.argtypes = [C.c_char_p, vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
         L.smvp_mm_read_coo_path.argtypes = [C.c_char_p, vp, ci, vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
         L.smvp_mm_expanded_count.argtypes = [vp, vp, ci, C.POINTER(ci)]
@@ -324,6 +325,13 @@ def partition_rows(row_ptr, parts):
     bounds = np.zeros(parts + 1, dtype=np.int32)
     _check(lib().smvp_partition_rows(_p(row_ptr), len(row_ptr) - 1, parts, _p(bounds)), "smvp_partition_rows")
     return bounds
+
+
+def vector_random(n, seed=67890):
+    """The operand of `--x random`: uniform [0, 1), a pure function of (seed, index)."""
+    x = np.zeros(max(n, 1), dtype=np.float64)
+    _check(lib().smvp_vector_random(_p(x), n, seed), "smvp_vector_random")
+    return x[:n]
 
 
 # ------------------------------------------------------------------- synthetic

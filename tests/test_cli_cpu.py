@@ -104,3 +104,26 @@ def test_stdout_tags_up_to_the_compute_step():
 def test_cisr_runs_without_a_gpu():                      # main-cli.c:1473-1476: host-only work (tests/test_cisr.py)
     rc, out, _ = run("-g", ob.fixture_path("ibm32.mtx"))
     assert rc == 0 and "memory_initialization_vector=" in out and "03ffffffff;" in out
+
+
+def test_x_and_dump_arrays_flags(tmp_path):
+    """--x ones|random and --dump-arrays are parsed (additive flags); without a GPU the run stops at device
+    selection, after the operand line.  The random operand is a documented pure function of (seed, index)."""
+    import numpy as np
+
+    f = ob.fixture_path("ibm32.mtx")
+    rc, out, _ = run("-c", "--x", "bogus", f)
+    assert rc == 1 and "[ERROR]\tUnknown operand (use ones or random)." in out
+    rc, out, _ = run("-c", "--x=random", "--dump-arrays", "-d", str(tmp_path), f)
+    assert "Random vector (uniform [0, 1), seed 67890) with dimensions [32, 1]" in out
+    rc, out, _ = run("-c", "--x", "ones", "-d", str(tmp_path), f)
+    assert "Ones vector with dimensions [32, 1]" in out
+    assert "--dump-arrays" in run("--help")[1] and "--x=ones" in run("--help")[1]
+    # the generator: top 53 bits of splitmix64's finaliser of seed + i, times 2^-53
+    x = sm.vector_random(1000, 67890)
+    z = (np.uint64(67890) + np.arange(1000, dtype=np.uint64) + np.uint64(0x9e3779b97f4a7c15))
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)
+    z = z ^ (z >> np.uint64(31))
+    assert np.array_equal(x, (z >> np.uint64(11)).astype(np.float64) * 2.0 ** -53)
+    assert 0.0 <= x.min() and x.max() < 1.0 and abs(x.mean() - 0.5) < 0.05

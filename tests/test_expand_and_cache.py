@@ -95,6 +95,53 @@ def test_cache_round_trip_and_staleness(tmp_path):
     assert e.value.code == sm.ERR_INVALID
 
 
+def _fnv1a(data, h=0xcbf29ce484222325):
+    for b in data:
+        h = ((h ^ b) * 0x100000001b3) & 0xffffffffffffffff
+    return h
+
+
+def test_crafted_cache_with_a_matching_checksum_is_refused(tmp_path):
+    """The payload checksum is no integrity guarantee: a cache whose row pointer decreases, or whose column index lies
+    outside the matrix, is refused even when its checksum has been recomputed to match (it would otherwise make
+    smvp_coo_from_csr write, and the kernels gather, out of bounds)."""
+    import struct
+
+    mtx = str(tmp_path / "m.mtx")
+    shutil.copy(ob.fixture_path("ibm32.mtx"), mtx)
+    tc, m, n, coo = sm.mm_read_coo(mtx)
+    rp, ci, v = sm.csr_from_coo(coo, m)
+    cache = mtx + ".smvpbin"
+    sm.cache_write_csr(cache, mtx, tc, m, n, rp, ci, v)
+    good = open(cache, "rb").read()
+
+    def crafted(rp2, ci2):
+        payload = rp2.astype("<i4").tobytes() + ci2.astype("<i4").tobytes() + v.astype("<f8").tobytes()
+        head = bytearray(good[:64])
+        head[48:56] = struct.pack("<Q", _fnv1a(payload))          # payload_fnv1a, right behind mtx_bytes / mtx_fnv1a
+        return bytes(head) + payload
+
+    open(cache, "wb").write(crafted(rp, ci))
+    sm.cache_read_csr(cache, mtx)                                       # the helper reproduces a valid file
+    bad_rp = rp.copy()
+    bad_rp[3], bad_rp[4] = rp[4] + 5, rp[3]                             # decreasing, still 0 ... nnz at the ends
+    bad_ci = ci.copy()
+    bad_ci[7] = n + 1000
+    neg_ci = ci.copy()
+    neg_ci[0] = -1
+    for rp2, ci2 in ((bad_rp, ci), (rp, bad_ci), (rp, neg_ci)):
+        open(cache, "wb").write(crafted(rp2, ci2))
+        with pytest.raises(sm.SmvpError) as e:
+            sm.cache_read_csr(cache, mtx)
+        assert e.value.code == sm.ERR_INVALID
+    with pytest.raises(sm.SmvpError):                                   # and the converter itself refuses such a row pointer
+        sm.coo_from_csr(m, bad_rp, ci, v)
+    # the CLI falls back to parsing the .mtx
+    open(cache, "wb").write(crafted(rp, bad_ci))
+    p = subprocess.run([sm.CLI_PATH, "-c", "--cache", "-d", str(tmp_path), mtx], capture_output=True, text=True)
+    assert "taken from the binary cache" not in p.stdout and "Non-zero numbers contained in matrix" in p.stdout
+
+
 def test_cli_cache_and_expand_flags_reach_the_loader(tmp_path):
     """No GPU here: the run stops at device selection, after the matrix has been loaded / cached."""
     mtx = str(tmp_path / "pwt.mtx")

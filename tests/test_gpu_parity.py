@@ -643,6 +643,89 @@ def test_cli_all_algs_end_to_end(torch, name, tmp_path):
     assert "TJDS algorithm" in got_t
 
 
+def test_cli_memplus_csr_and_tjds_n1000(torch, tmp_path):
+    """BASELINE configs 2 and 3 literally: `memplus.mtx -c -t -n 1000` through the command line.  The report's "%g" text
+    equals the committed report's on every row summed in the serial order (up to 32 entries: one lane) and on every
+    well-conditioned longer row; both reports carry 1000 products' statistics; stdout says how the window was taken."""
+    path = ob.fixture_path("memplus.mtx")
+    p = subprocess.run([sm.CLI_PATH, "-c", "-t", "-n", "1000", "-d", str(tmp_path), path], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    for tag in ("Calculating 1000 iterations of SMVP CSR.", "Calculating 1000 iterations of SMVP TJDS.",
+                "CSR timing:", "TJDS timing:", "in the report file", "host wall per product"):
+        assert tag in p.stdout, tag
+    files = sorted(os.listdir(tmp_path))
+    assert len(files) == 2
+    m, n, coo = load("memplus.mtx")
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, np.ones(n))
+    scale = row_scale(row_ptr, col_ind, val, np.ones(n))
+    lens = np.diff(row_ptr)
+    want = ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_%s.txt" % REPORTS["memplus.mtx"][0]))
+    well = np.abs(ref) > 1e-6 * scale
+    for f, alg in zip(files, ("CSR", "TJDS")):
+        text = open(tmp_path / f).read()
+        assert "%s algorithm" % alg in text and "Compute times for 1000 iterations:" in text
+        got = ob.report_y_lines(text)
+        assert len(got) == m
+        if alg == "CSR":
+            assert all(got[i] == want[i] for i in np.flatnonzero(lens <= 32))
+        assert sum(got[i] != want[i] for i in np.flatnonzero(well)) <= 2       # a last-digit rounding tie at most
+        y = np.array([float(v) for v in got])
+        assert np.all(np.abs(y - ref) <= 1e-5 * scale + 1e-300)                # "%g" keeps six digits
+
+
+def test_cli_dump_arrays_and_random_operand(torch, tmp_path):
+    """--dump-arrays prints the reference's debug dumps (main-cli.c:374-394, 458-466, 870-892, 969-992, 1150-1158,
+    1166-1191): on ibm32 the reordering table and start_pos are the ones recorded from the reference itself (SURVEY 8(a));
+    --x random multiplies by the documented random operand."""
+    from test_oracle_golden import IBM32_PERM, IBM32_START_POS
+
+    path = ob.fixture_path("ibm32.mtx")
+    m, n, coo = load("ibm32.mtx")
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    p = subprocess.run([sm.CLI_PATH, "-c", "-t", "--dump-arrays", "-n", "3", "-d", str(tmp_path), path], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = p.stdout
+
+    def listed(head):
+        i = out.index(head) + len(head)
+        return [t for t in out[i:out.index("]", i)].replace("\n", " ").split(", ") if t.strip()]
+
+    assert [int(t) for t in listed("[DEBUG]\tCSR JIT row_ptr:\n\t[")] == row_ptr.tolist()
+    assert [int(t) for t in listed("[DEBUG]\tCSR JIT col_ind:\n\t[")] == col_ind.tolist()
+    assert listed("[DEBUG]\tCSR JIT val:\n\t[") == ["%g" % v for v in val]
+    want = ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_%s.txt" % REPORTS["ibm32.mtx"][0]))
+    for head in ("[DEBUG]\tCSR JIT Vector Out:\n\t[", "[DEBUG]\tCSR Output Vector:\n\t[", "[DEBUG]\tTJDS PHASE 8: Output Vector:\n\t["):
+        assert listed(head) == want, head
+    assert "[DEBUG]\tCSR Iterations: 3\n[DEBUG]\tCSR fInputRows: 32\n[DEBUG]\tCSR fInputNonZeros: 126\n" in out
+    assert len(listed("[DEBUG]\tCSR Times:\n\t[")) == 3
+    assert [int(t) for t in listed("origCol\t[")] == IBM32_PERM
+    assert [int(t) for t in listed("\tstart_pos:\t[")] == IBM32_START_POS
+    assert "num_tjdiag (count, not 0-index):\t7" in out
+    t = sm.tjds_from_coo(coo, m, n)
+    assert [int(x) for x in listed("\trow_ind:\t[")] == t.row_ind.tolist()
+    assert listed("\tval:\t\t[") == ["%g" % v for v in t.val]
+    assert [int(x) for x in listed("colLen\t[")] == np.bincount(coo["col"], minlength=n)[t.perm].tolist()
+    # the reference's own count with --ref-quirks (length of original column 0): start_pos over 6 + 1 entries
+    q = subprocess.run([sm.CLI_PATH, "-t", "--ref-quirks", "--dump-arrays", "-n", "1", "-d", str(tmp_path), path],
+                       capture_output=True, text=True).stdout
+    assert "num_tjdiag (count, not 0-index):\t6" in q
+    # without the flag nothing of it is printed
+    quiet = subprocess.run([sm.CLI_PATH, "-c", "-n", "1", "-d", str(tmp_path), path], capture_output=True, text=True).stdout
+    assert "[DEBUG]" not in quiet
+    # --x random
+    before = set(os.listdir(tmp_path))
+    r = subprocess.run([sm.CLI_PATH, "-c", "-t", "--x", "random", "-n", "2", "-d", str(tmp_path), path], capture_output=True, text=True)
+    assert r.returncode == 0 and "Random vector" in r.stdout
+    x = sm.vector_random(n, 67890)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+    new = sorted(set(os.listdir(tmp_path)) - before)
+    assert len(new) == 2
+    for f in new:
+        got = np.array([float(v) for v in ob.report_y_lines(open(tmp_path / f).read())])
+        assert np.all(np.abs(got - ref) <= 1e-5 * row_scale(row_ptr, col_ind, val, x))
+
+
 def test_cli_ref_quirks_reproduces_reference_tjds_report(torch, tmp_path):
     name = "curtis54.mtx"
     p = subprocess.run([sm.CLI_PATH, "-t", "--ref-quirks", "-n", "5", "-d", str(tmp_path), ob.fixture_path(name)],
@@ -922,6 +1005,7 @@ def test_sharded_unequal_blocks_on_several_gpus(torch, ngpus):
         ref = ob.csr_spmv(row_ptr, col_ind, val, x)
         scale = row_scale(row_ptr, col_ind, val, x)
         for fmt in ("csr", "tjds"):
+            got = {}
             for gather in (sm.GATHER_OVERLAPPED, sm.GATHER_AFTER):
                 S = sm.ShardedMatrix(fmt, ngpus, rows, cols, coo=coo, csr=(row_ptr, col_ind, val), chunks=3)
                 S.set_x(x)
@@ -929,7 +1013,19 @@ def test_sharded_unequal_blocks_on_several_gpus(torch, ngpus):
                 S.synchronize()
                 for slot in range(ngpus):
                     assert_close(S.get_y(slot, gathered=True), ref, scale)
+                got[gather] = S.get_y(0, gathered=True)
                 S.close()
+            assert np.array_equal(got[sm.GATHER_OVERLAPPED], got[sm.GATHER_AFTER])    # the same bits either way
+
+
+def test_device_timing_is_refused_for_a_sharded_run(torch):
+    """The in-kernel stamps time one launch on one GPU; a sharded product is several launches on several GPUs: asking for
+    them is an error, not silently something else (the check comes before any GPU is opened)."""
+    m, n, coo = load("ibm32.mtx")
+    for fn in (sm.csr_compute, sm.tjds_compute):
+        with pytest.raises(sm.SmvpError) as e:
+            fn(coo, m, n, iters=2, ngpus=2, timing=sm.TIMING_DEVICE)
+        assert e.value.code == sm.ERR_UNSUPPORTED
 
 
 def test_calls_leave_the_callers_device_alone(torch):

@@ -7,11 +7,11 @@ TAG=${1:-r02}; shift || true
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/cli_$TAG
 mkdir -p "$OUT/reports"
-for m in memplus pwt; do
-  [ -f /tmp/$m.mtx ] || gunzip -c $R/tests/golden/sample-data/$m.mtx.gz > /tmp/$m.mtx
+for m in ibm32 memplus pwt; do
+  [ -f /tmp/$m.mtx ] || { [ -f $R/tests/golden/sample-data/$m.mtx ] && cp $R/tests/golden/sample-data/$m.mtx /tmp/$m.mtx || gunzip -c $R/tests/golden/sample-data/$m.mtx.gz > /tmp/$m.mtx; }
 done
 cd /tmp; export TMPDIR=/tmp
-for m in memplus pwt; do
+for m in ibm32 memplus pwt; do
   $R/smvp-toolkit_amd/bin/smvp-toolkit-cli -c -t -n 1000 -d "$OUT/reports" "$@" /tmp/$m.mtx > "$OUT/${m}_plain.log" 2>&1 || echo "plain run of $m failed"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$m" -o t -- \
       $R/smvp-toolkit_amd/bin/smvp-toolkit-cli -c -t -n 1000 -d "$OUT/reports" "$@" /tmp/$m.mtx > "$OUT/${m}_rocprof.log" 2>&1 || echo "rocprof run of $m failed"
