@@ -81,6 +81,9 @@ def main():
             A.spmv(dx, dy)
             torch.cuda.synchronize()
             check(dy.cpu().numpy()[:rows], "csr kernel %d param %d" % (k, p))
+            if k == sm.CSR_KERNEL_COLSWEEP and not np.array_equal(dy.cpu().numpy()[:rows], ref):   # the sweep is the serial order
+                bad += 1
+                print("NOT BIT-IDENTICAL seed %d: colsweep param %d" % (seed, p), flush=True)
         A.close()
         coo = sm.make_coo(np.repeat(np.arange(rows), np.diff(row_ptr)), col_ind, val)
         coo = coo[np.random.default_rng(seed).permutation(len(coo))]
@@ -96,6 +99,17 @@ def main():
                 T.spmv(dy)
                 torch.cuda.synchronize()
                 check(dy.cpu().numpy()[:rows], "tjds %s tile %d" % (index, tile))
+                if index == "sorted":        # the value cache never changes a bit
+                    first = dy.clone()
+                    for cache in (0, 1, 2, 8):
+                        T.set_value_cache(cache)
+                        dy.fill_(float("nan"))
+                        T.spmv(dy)
+                        torch.cuda.synchronize()
+                        if not torch.equal(dy[:rows], first[:rows]):
+                            bad += 1
+                            print("NOT BIT-IDENTICAL seed %d: tjds tile %d cache %d" % (seed, tile, cache), flush=True)
+                    T.set_value_cache(4)
             for mode in (sm.TJDS_MODE_TWO_PHASE, sm.TJDS_MODE_ATOMIC):
                 T.set_mode(mode)
                 dy = torch.full((max(rows, 1),), float("nan"), dtype=torch.float64, device="cuda")
