@@ -951,10 +951,8 @@ def main():
         if rank == 0:
             try:
                 c_layer = measure_c_layer(sm, args.rows, world, max(5, args.steps // 10), rank)
-            except SystemExit:
-                raise
-            except Exception as e:
-                c_layer = {"error": str(e)}
+            except BaseException as e:   # a wrong result included: the other ranks are waiting on the barrier below,
+                c_layer = {"error": str(e) or type(e).__name__}    # so this leg reports its failure instead of ending the run
         if park is not None:
             dist.barrier(group=park)     # the other ranks wait here, on the CPU, with their GPUs idle
 
