@@ -23,6 +23,10 @@ int build_colsweep_plan(const int *d_row_ptr, const int *d_col_ind, const double
 int sort_tile_windows(const int *d_pos, int nnz, int tile, const int *d_start_pos, int num_diag, int slot_bits,
                       const double *d_val, int cache_min_tiles, int *d_pos_sorted, int *d_meta, int *d_cache_ptr,
                       double **d_val_cache, int *cached_total, ihipStream_t *stream);
+int build_tile_half_streams(const int *d_pos, int nnz, int tile, const int *d_start_pos, int num_diag, const double *d_val,
+                            int cache_min_tiles, int *d_pos_sorted, unsigned short *d_meta16, int *d_cache_ptr, int *d_run_ptr,
+                            double **d_val_cache, int **d_run_sp, unsigned short **d_group_run, int *cached_total,
+                            int *runs_total, ihipStream_t *stream);
 int build_tile_overflow(const int *d_pos, const int *d_ovf_ptr, int total, int ntiles, int tile, int nnz,
                         const int *d_start_pos, int num_diag, int *d_ovf_pos, int *d_ovf_k, ihipStream_t *stream);
 }

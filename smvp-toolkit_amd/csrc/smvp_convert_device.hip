@@ -412,6 +412,69 @@ __global__ __launch_bounds__(256) void overflow_entries(const int *__restrict__ 
 
 }  // namespace
 
+namespace {
+
+// kFlavorTjdsH, pass 1 over the sorted windows.  A RUN is a stretch of one tile's sorted entries that lie in one jagged
+// diagonal (the tile's cached entries, which come last and carry their column, form one more run): head[e] = 1 where a run
+// starts, diag[e] = the entry's diagonal (-1: cached).
+__global__ __launch_bounds__(256) void diagonal_run_heads(const u64 *__restrict__ key, int nnz, int tile,
+                                                          const int *__restrict__ start_pos, int num_diag,
+                                                          int *__restrict__ diag, int *__restrict__ head,
+                                                          int *__restrict__ runs_in_tile)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nnz)
+        return;
+    const bool cached = (key[e] >> 32) & 1u;
+    const int d = cached ? -1 : diagonal_of(start_pos, num_diag, (int)(unsigned)(key[e] & 0xffffffffu));
+    int h = 1;
+    if (e % tile != 0) {
+        const bool pc = (key[e - 1] >> 32) & 1u;
+        const int pd = pc ? -1 : diagonal_of(start_pos, num_diag, (int)(unsigned)(key[e - 1] & 0xffffffffu));
+        h = pd != d ? 1 : 0;
+    }
+    diag[e] = d;
+    head[e] = h;
+    if (h)
+        atomicAdd(&runs_in_tile[e / tile], 1);
+}
+
+// pass 2: position (or, cached, column) per entry as in window_streams; a 16-bit word slot | run number mod 32 << 11;
+// per run the start_pos of its diagonal (0 for the cached run: column - 0); per group of 32 entries its first entry's run
+__global__ __launch_bounds__(256) void half_streams(const u64 *__restrict__ key, const unsigned *__restrict__ slot, int nnz,
+                                                    int tile, const int *__restrict__ start_pos, int num_diag,
+                                                    const int *__restrict__ diag, const int *__restrict__ head,
+                                                    const int *__restrict__ run_id, const int *__restrict__ run_ptr,
+                                                    const int *__restrict__ cache_ptr, const double *__restrict__ val,
+                                                    int *__restrict__ pos_sorted, unsigned short *__restrict__ meta16,
+                                                    int *__restrict__ run_sp, unsigned short *__restrict__ group_run,
+                                                    double *__restrict__ val_cache)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nnz)
+        return;
+    const int b = e / tile, idx = e % tile;
+    const int p = (int)(unsigned)(key[e] & 0xffffffffu);
+    const int d = diag[e];
+    const int r = run_id[e] - 1;  // run_id = inclusive scan of head
+    const int local = r - run_ptr[b];
+    if (d < 0) {  // cached: its column, and its value into the tile's run of the cache
+        const long long tile_end = (long long)(b + 1) * tile < nnz ? (long long)(b + 1) * tile : nnz;
+        const int c0 = cache_ptr[b], c1 = cache_ptr[b + 1];
+        pos_sorted[e] = p - start_pos[diagonal_of(start_pos, num_diag, p)];
+        val_cache[c0 + (e - (int)(tile_end - (c1 - c0)))] = val[p];
+    } else {
+        pos_sorted[e] = p;
+    }
+    if (head[e])
+        run_sp[r] = d < 0 ? 0 : start_pos[d];
+    if (idx % 32 == 0)
+        group_run[(size_t)b * (tile / 32) + idx / 32] = (unsigned short)local;
+    meta16[e] = (unsigned short)(slot[e] | ((unsigned)(local & 31) << 11));
+}
+
+}  // namespace
+
 namespace smvp {
 
 // kFlavorTjdsS: the row-major stream `d_pos` cut into windows of `tile` entries, every window sorted by TJDS position;
@@ -480,6 +543,89 @@ int sort_tile_windows(const int *d_pos, int nnz, int tile, const int *d_start_po
     hipLaunchKernelGGL(window_streams, dim3(blocks_for(nnz)), dim3(256), 0, st, k1, s1, nnz, tile, d_start_pos, num_diag, slot_bits,
                        d_cache_ptr, d_val, d_pos_sorted, d_meta, *d_val_cache);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    return SMVP_OK;
+}
+
+// kFlavorTjdsH: like sort_tile_windows, but the entry's second word is 16 bits (slot | run hint) and the start_pos of its
+// diagonal comes from the tile's run table.  Allocates *d_val_cache, *d_run_sp, *d_group_run (hipFree by the caller);
+// d_cache_ptr / d_run_ptr have ntiles + 1 entries.
+int build_tile_half_streams(const int *d_pos, int nnz, int tile, const int *d_start_pos, int num_diag, const double *d_val,
+                            int cache_min_tiles, int *d_pos_sorted, unsigned short *d_meta16, int *d_cache_ptr, int *d_run_ptr,
+                            double **d_val_cache, int **d_run_sp, unsigned short **d_group_run, int *cached_total,
+                            int *runs_total, hipStream_t st)
+{
+    const int ntiles = std::max(1, (int)(((long long)nnz + tile - 1) / tile));
+    *d_val_cache = nullptr, *d_run_sp = nullptr, *d_group_run = nullptr;
+    *cached_total = *runs_total = 0;
+    if (tile % 32 != 0 || tile > 2048)
+        return smvp::fail(SMVP_ERR_UNSUPPORTED, "build_tile_half_streams: tile %d does not fit the 16-bit word", tile);
+    HIP_TRY(hipMemsetAsync(d_cache_ptr, 0, sizeof(int) * ((size_t)ntiles + 1), st));
+    HIP_TRY(hipMemsetAsync(d_run_ptr, 0, sizeof(int) * ((size_t)ntiles + 1), st));
+    Scratch sc;
+    u64 *k0, *k1;
+    unsigned *s0, *s1;
+    int *count, *rcount, *dg, *head, *rid;
+    unsigned char *flag = nullptr;
+    const size_t n = (size_t)std::max(nnz, 1);
+    HIP_TRY(sc.get(&k0, n));
+    HIP_TRY(sc.get(&k1, n));
+    HIP_TRY(sc.get(&s0, n));
+    HIP_TRY(sc.get(&s1, n));
+    HIP_TRY(sc.get(&dg, n));
+    HIP_TRY(sc.get(&head, n));
+    HIP_TRY(sc.get(&rid, n));
+    HIP_TRY(sc.get(&count, (size_t)ntiles + 1));
+    HIP_TRY(sc.get(&rcount, (size_t)ntiles + 1));
+    HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * ((size_t)ntiles + 1), st));
+    HIP_TRY(hipMemsetAsync(rcount, 0, sizeof(int) * ((size_t)ntiles + 1), st));
+    int total = 0, nruns = 0;
+    if (nnz > 0) {
+        if (cache_min_tiles > 0) {
+            int *where;
+            const int nlines = (nnz + 15) / 16;
+            HIP_TRY(sc.get(&where, n));
+            HIP_TRY(sc.get(&flag, (size_t)nlines));
+            hipLaunchKernelGGL(invert_positions, dim3(blocks_for(nnz)), dim3(256), 0, st, d_pos, nnz, where);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(mark_scattered_lines, dim3(blocks_for(nlines)), dim3(256), 0, st, where, nnz, tile, cache_min_tiles, flag);
+            HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(window_keys, dim3(blocks_for(nnz)), dim3(256), 0, st, d_pos, nnz, tile, flag, k0, s0, count);
+        HIP_TRY(hipGetLastError());
+        const unsigned bits = 33u + (unsigned)bits_for(ntiles + 1);
+        size_t tmp_bytes = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, s0, s1, (size_t)nnz, 0u, bits, st));
+        char *tmp;
+        HIP_TRY(sc.get(&tmp, tmp_bytes));
+        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, s0, s1, (size_t)nnz, 0u, bits, st));
+        hipLaunchKernelGGL(diagonal_run_heads, dim3(blocks_for(nnz)), dim3(256), 0, st, k1, nnz, tile, d_start_pos, num_diag, dg, head, rcount);
+        HIP_TRY(hipGetLastError());
+        size_t scan_bytes = 0, scan2 = 0;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, count, d_cache_ptr, 0, (size_t)ntiles + 1, rocprim::plus<int>(), st));
+        HIP_TRY(rocprim::inclusive_scan(nullptr, scan2, head, rid, (size_t)nnz, rocprim::plus<int>(), st));
+        char *scan_tmp;
+        HIP_TRY(sc.get(&scan_tmp, std::max(scan_bytes, scan2)));
+        HIP_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, count, d_cache_ptr, 0, (size_t)ntiles + 1, rocprim::plus<int>(), st));
+        HIP_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, rcount, d_run_ptr, 0, (size_t)ntiles + 1, rocprim::plus<int>(), st));
+        HIP_TRY(rocprim::inclusive_scan(scan_tmp, scan2, head, rid, (size_t)nnz, rocprim::plus<int>(), st));
+        HIP_TRY(hipMemcpyAsync(&total, d_cache_ptr + ntiles, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&nruns, d_run_ptr + ntiles, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    *cached_total = total;
+    *runs_total = nruns;
+    const size_t groups = (size_t)ntiles * (size_t)(tile / 32);
+    if (hipMalloc((void **)d_val_cache, sizeof(double) * (size_t)std::max(total, 4)) != hipSuccess ||
+        hipMalloc((void **)d_run_sp, sizeof(int) * (size_t)std::max(nruns, 4)) != hipSuccess ||
+        hipMalloc((void **)d_group_run, sizeof(unsigned short) * std::max<size_t>(groups, 4)) != hipSuccess)
+        return smvp::fail(SMVP_ERR_ALLOC, "build_tile_half_streams: cannot allocate the run tables (%d runs, %d cached values)", nruns, total);
+    HIP_TRY(hipMemsetAsync(*d_group_run, 0, sizeof(unsigned short) * std::max<size_t>(groups, 4), st));
+    if (nnz > 0) {
+        hipLaunchKernelGGL(half_streams, dim3(blocks_for(nnz)), dim3(256), 0, st, k1, s1, nnz, tile, d_start_pos, num_diag, dg, head, rid,
+                           d_run_ptr, d_cache_ptr, d_val, d_pos_sorted, d_meta16, *d_run_sp, *d_group_run, *d_val_cache);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipStreamSynchronize(st));
     return SMVP_OK;
 }

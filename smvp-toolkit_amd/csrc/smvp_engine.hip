@@ -129,6 +129,10 @@ struct smvp_csr {
     int cache_min_tiles = 4, cached_total = 0;
     int *d_cache_ptr = nullptr;
     double *d_val_cache = nullptr;
+    // TjdsH: the 16-bit second word of every entry, the tiles' runs (start_pos of each run's diagonal), each group of 32's run
+    unsigned short *d_meta16 = nullptr, *d_group_run = nullptr;
+    int *d_run_ptr = nullptr, *d_run_sp = nullptr;
+    int runs_total = 0;
     int kernel = SMVP_CSR_KERNEL_AUTO;  // resolved: never AUTO once a plan exists
     int lanes_per_row = 64;             // VECTOR
     int vpt = 4;                        // STREAM: entries per thread (tile = 256 * vpt)
@@ -265,12 +269,15 @@ void free_stream_plan(smvp_csr *h)
     if (h->d_tile_next)
         (void)hipFree(h->d_tile_next);
     for (void *p : {(void *)h->d_pos_sorted, (void *)h->d_meta, (void *)h->d_ovf_ptr, (void *)h->d_ovf_pos, (void *)h->d_ovf_k,
-                    (void *)h->d_cache_ptr, (void *)h->d_val_cache})
+                    (void *)h->d_cache_ptr, (void *)h->d_val_cache, (void *)h->d_meta16, (void *)h->d_group_run,
+                    (void *)h->d_run_ptr, (void *)h->d_run_sp})
         if (p)
             (void)hipFree(p);
     h->d_pos_sorted = h->d_meta = h->d_ovf_ptr = h->d_ovf_pos = h->d_ovf_k = h->d_cache_ptr = nullptr;
+    h->d_run_ptr = h->d_run_sp = nullptr;
+    h->d_meta16 = h->d_group_run = nullptr;
     h->d_val_cache = nullptr;
-    h->cached_total = 0;
+    h->cached_total = h->runs_total = 0;
     h->d_tile_row = h->d_carry_row = h->d_tile_next = nullptr;
     h->d_carry = nullptr;
     h->ntiles = 0;
@@ -311,7 +318,7 @@ int build_stream_plan(smvp_csr *h)
         HIP_TRY(hipMemset(h->d_carry, 0, std::max(ntiles, 1) * sizeof(double)));
     }
     h->ntiles = ntiles;
-    if (h->flavor == smvp::kFlavorTjdsS) {
+    if (h->flavor == smvp::kFlavorTjdsS || h->flavor == smvp::kFlavorTjdsH) {
         // every tile's entries in TJDS order + what each tile reads past its end, in row order
         std::vector<int> ovf_ptr((size_t)ntiles + 1, 0);
         for (int b = 0; b < ntiles; ++b) {
@@ -324,15 +331,27 @@ int build_stream_plan(smvp_csr *h)
             return rc;
         const size_t n = (size_t)std::max(h->nnz, 4), m = (size_t)std::max(total, 4);
         if (hipMalloc((void **)&h->d_pos_sorted, n * sizeof(int)) != hipSuccess ||
-            hipMalloc((void **)&h->d_meta, n * sizeof(int)) != hipSuccess ||
             hipMalloc((void **)&h->d_ovf_pos, m * sizeof(int)) != hipSuccess ||
             hipMalloc((void **)&h->d_ovf_k, m * sizeof(int)) != hipSuccess ||
             hipMalloc((void **)&h->d_cache_ptr, ((size_t)ntiles + 2) * sizeof(int)) != hipSuccess)
             return smvp::fail(SMVP_ERR_ALLOC, "cannot allocate the tile-ordered TJDS streams");
-        if (int rc = smvp::sort_tile_windows(h->d_pos, h->nnz, tile, h->d_start_pos, h->num_diag, smvp::kSlotBits, h->d_val,
-                                             h->cache_min_tiles, h->d_pos_sorted, h->d_meta, h->d_cache_ptr, &h->d_val_cache,
-                                             &h->cached_total, nullptr))
-            return rc;
+        if (h->flavor == smvp::kFlavorTjdsH) {
+            if (hipMalloc((void **)&h->d_meta16, n * sizeof(unsigned short)) != hipSuccess ||
+                hipMalloc((void **)&h->d_run_ptr, ((size_t)ntiles + 2) * sizeof(int)) != hipSuccess)
+                return smvp::fail(SMVP_ERR_ALLOC, "cannot allocate the tile-ordered TJDS streams");
+            if (int rc = smvp::build_tile_half_streams(h->d_pos, h->nnz, tile, h->d_start_pos, h->num_diag, h->d_val,
+                                                       h->cache_min_tiles, h->d_pos_sorted, h->d_meta16, h->d_cache_ptr,
+                                                       h->d_run_ptr, &h->d_val_cache, &h->d_run_sp, &h->d_group_run,
+                                                       &h->cached_total, &h->runs_total, nullptr))
+                return rc;
+        } else {
+            if (hipMalloc((void **)&h->d_meta, n * sizeof(int)) != hipSuccess)
+                return smvp::fail(SMVP_ERR_ALLOC, "cannot allocate the tile-ordered TJDS streams");
+            if (int rc = smvp::sort_tile_windows(h->d_pos, h->nnz, tile, h->d_start_pos, h->num_diag, smvp::kSlotBits, h->d_val,
+                                                 h->cache_min_tiles, h->d_pos_sorted, h->d_meta, h->d_cache_ptr, &h->d_val_cache,
+                                                 &h->cached_total, nullptr))
+                return rc;
+        }
         if (int rc = smvp::build_tile_overflow(h->d_pos, h->d_ovf_ptr, total, ntiles, tile, h->nnz, h->d_start_pos,
                                                h->num_diag, h->d_ovf_pos, h->d_ovf_k, nullptr))
             return rc;
@@ -379,7 +398,7 @@ bool choose_csr_kernel(smvp_csr *h, int kernel, int param)
         int tile = param > 0 ? param : 0;
         if (tile == 0) {  // 1024 measured 1-4 % ahead of 2048 on memplus x944 and pwt x459; 256-entry tiles when
             tile = (kernel == SMVP_CSR_KERNEL_STREAM && h->nnz < 512 * 1024) ? 256 : 1024;  // 1024 would leave CUs idle
-            if (h->flavor == smvp::kFlavorTjdsS && tile == 1024 && h->nnz >= 48 * 1024 * 1024)
+            if ((h->flavor == smvp::kFlavorTjdsS || h->flavor == smvp::kFlavorTjdsH) && tile == 1024 && h->nnz >= 48 * 1024 * 1024)
                 tile = 2048;  // more entries per val line inside a tile: 0.553 vs 0.588 ms on memplus x944 (119 M entries);
                               // below that 1024 wins (14 M entries: 0.0630 vs 0.0663 ms; 3.5 M: 0.0201 vs 0.0219)
         }
@@ -404,7 +423,7 @@ static int csr_create_impl(smvp_csr_t **out, int device, int rows, int cols, int
     const bool unit_val = flavor == smvp::kFlavorUnit;
     const bool plain = flavor == smvp::kFlavorCsr;
     if (!out || rows < 0 || cols < 0 || nnz < 0 || !row_ptr ||
-        (nnz > 0 && ((!col_ind && flavor != smvp::kFlavorTjdsS) || (!val && !unit_val))))
+        (nnz > 0 && ((!col_ind && flavor != smvp::kFlavorTjdsS && flavor != smvp::kFlavorTjdsH) || (!val && !unit_val))))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: bad argument");
     if (mem_kind != SMVP_MEM_HOST && mem_kind != SMVP_MEM_DEVICE)
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: bad mem_kind");
@@ -558,10 +577,11 @@ static int csr_spmv_impl(smvp_csr_t *h, const double *d_x, double *d_y, void *st
         l.row_ptr = h->d_row_ptr, l.col_ind = h->d_col_ind, l.val = h->d_val, l.x = d_x, l.y = d_y;
         l.tile_row = h->d_tile_row, l.tile_next = h->d_tile_next;
         l.pos = h->d_pos, l.start_pos = h->d_start_pos;
-        if (h->flavor == smvp::kFlavorTjdsS) {
+        if (h->flavor == smvp::kFlavorTjdsS || h->flavor == smvp::kFlavorTjdsH) {
             l.pos = h->d_pos_sorted, l.col_ind = h->d_meta;
             l.ovf_ptr = h->d_ovf_ptr, l.ovf_pos = h->d_ovf_pos, l.ovf_k = h->d_ovf_k;
             l.cache_ptr = h->d_cache_ptr, l.val_cache = h->d_val_cache;
+            l.meta16 = h->d_meta16, l.group_run = h->d_group_run, l.run_ptr = h->d_run_ptr, l.run_sp = h->d_run_sp;
         }
         l.stamps = stamps;
         l.rows = h->rows, l.nnz = h->nnz, l.ntiles = h->ntiles;
@@ -728,16 +748,19 @@ void free_row_gather(smvp_tjds *h)
     h->d_rg_ptr = h->d_rg_pos = h->d_rg_k = nullptr;
 }
 
-// How the row-gather stream names an entry's permuted column: tile-ordered streams with packed slot | diagonal words
-// (kFlavorTjdsS) when the diagonals fit 21 bits, else 32-bit permuted columns in row order (kFlavorTjdsK);
-// SMVP_TJDS_INDEX=k32|sorted overrides (development switch).
+// How the row-gather stream names an entry: tile-ordered streams with the position and a 16-bit slot | run-hint word per
+// entry plus the tiles' run tables (kFlavorTjdsH, 6 bytes of index per entry: the default); the same order with a 32-bit
+// slot | diagonal word (kFlavorTjdsS, 8 bytes; needs the diagonals to fit 21 bits); or 32-bit permuted columns in row
+// order (kFlavorTjdsK).  SMVP_TJDS_INDEX=half|sorted|k32 selects (development switch; the tests run all three).
 int row_gather_index(const smvp_tjds *h)
 {
     const char *e = getenv("SMVP_TJDS_INDEX");
     const bool fits_sorted = ((long long)std::max(h->num_diag - 1, 0) >> (32 - smvp::kSlotBits)) == 0;
     if (e && !strcmp(e, "k32"))
         return smvp::kFlavorTjdsK;
-    return fits_sorted ? smvp::kFlavorTjdsS : smvp::kFlavorTjdsK;
+    if (e && !strcmp(e, "sorted") && fits_sorted)
+        return smvp::kFlavorTjdsS;
+    return smvp::kFlavorTjdsH;
 }
 
 int ensure_row_gather(smvp_tjds *h)
@@ -973,7 +996,7 @@ extern "C" int smvp_tjds_set_value_cache(smvp_tjds_t *h, int min_tiles)
 {
     if (!h || !h->rg || min_tiles < 0 || min_tiles > 16)
         return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_set_value_cache: needs the row-gather plan and 0 <= min_tiles <= 16");
-    if (h->rg->flavor != smvp::kFlavorTjdsS)
+    if (h->rg->flavor != smvp::kFlavorTjdsS && h->rg->flavor != smvp::kFlavorTjdsH)
         return min_tiles == 0 ? (int)SMVP_OK
                               : smvp::fail(SMVP_ERR_UNSUPPORTED, "the value cache belongs to the tile-ordered TJDS stream");
     DeviceScope on(h->device);
@@ -985,7 +1008,7 @@ extern "C" int smvp_tjds_get_value_cache(const smvp_tjds_t *h, int *min_tiles, l
 {
     if (!h)
         return smvp::fail(SMVP_ERR_INVALID, "null handle");
-    const bool on = h->rg && h->rg->flavor == smvp::kFlavorTjdsS;
+    const bool on = h->rg && (h->rg->flavor == smvp::kFlavorTjdsS || h->rg->flavor == smvp::kFlavorTjdsH);
     if (min_tiles)
         *min_tiles = on ? h->rg->cache_min_tiles : 0;
     if (cached_entries)

@@ -29,6 +29,8 @@ constexpr int kFlavorCsr = 0;    // val[j] * x[col_ind[j]]
 constexpr int kFlavorUnit = 1;   // x[col_ind[j]]
 constexpr int kFlavorTjdsK = 2;  // val[pos[j]] * x_perm[col_ind[j]]   (col_ind = permuted column k)
 constexpr int kFlavorTjdsS = 3;  // the same entries, every tile's in TJDS order; col_ind = LDS slot | diagonal << kSlotBits
+constexpr int kFlavorTjdsH = 4;  // kFlavorTjdsS with a 16-bit second word: slot | run hint << 11; the start_pos of the entry's
+                                 // diagonal comes from the tile's run table (6 bytes of index per entry instead of 8)
 constexpr int kSlotBits = 11;    // a tile holds at most 2048 entries
 
 struct OwnerLaunch {
@@ -42,6 +44,8 @@ struct OwnerLaunch {
     const int *ovf_ptr = nullptr, *ovf_pos = nullptr, *ovf_k = nullptr;  // kFlavorTjdsS
     const int *cache_ptr = nullptr;                                      // kFlavorTjdsS
     const double *val_cache = nullptr;
+    const unsigned short *meta16 = nullptr, *group_run = nullptr;        // kFlavorTjdsH
+    const int *run_ptr = nullptr, *run_sp = nullptr;
     int rows = 0, nnz = 0, ntiles = 0;
 };
 hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hipStream_t stream);

@@ -208,6 +208,12 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_tiles(
 //                  lanes read neighbouring val / x_perm entries, lane t takes entries t, t + 256, ... of the tile --
 //                  and each product goes to the LDS slot of its row-major place (`col_ind` holds slot | diagonal << 11);
 //                  the entries a tile needs from beyond its end are kept a second time in row order (ovf_*)
+//   kFlavorTjdsH   kFlavorTjdsS with 6 bytes of index per entry instead of 8: the position stays a 32-bit word (the val
+//                  gather goes out the moment it arrives, as before), the second word shrinks to 16 bits -- LDS slot | the
+//                  number, modulo 32, of the entry's RUN: a stretch of the tile's sorted entries inside one jagged diagonal.
+//                  The tile's run table holds start_pos of each run's diagonal; an entry finds its run from the run of its
+//                  group of 32 entries (`group_run`, one 16-bit word per group) and the 5-bit hint, reads start_pos there
+//                  instead of start_pos[diagonal], and the x gather follows: the same two dependent steps as before.
 // ---------------------------------------------------------------------------
 typedef int int4v __attribute__((ext_vector_type(4)));               // clang vectors: what the non-temporal builtins take
 
@@ -221,6 +227,10 @@ struct OwnerExtra {
     const int *ovf_k;               // TjdsS: ... and permuted column of the entries [e, tile_next) of each tile, row order
     const int *cache_ptr;           // TjdsS: ntiles + 1 bounds of the tiles' runs in val_cache (a tile's last entries)
     const double *val_cache;        // TjdsS: values of the entries whose val lines scatter over many tiles, tile by tile
+    const unsigned short *meta16;   // TjdsH: slot | run hint << kSlotBits per entry
+    const unsigned short *group_run;  // TjdsH: per tile and group of 32 entries, the run (inside the tile) of its first entry
+    const int *run_ptr;             // TjdsH: ntiles + 1 bounds of the tiles' runs in run_sp
+    const int *run_sp;              // TjdsH: start_pos of every run's diagonal (0 for a tile's run of cached entries)
     unsigned long long *stamps;     // STAMPED: per-wave {first, last} wall-clock ticks of this launch
     int stream_nt;                  // TjdsS: load the pos / slot streams non-temporally (development switch)
 };
@@ -256,7 +266,7 @@ __device__ __forceinline__ double owner_product_slow(const OwnerArgs &a, long lo
 template <int FLAVOR>
 __device__ __forceinline__ double owner_overflow_product(const OwnerArgs &a, int ovf_base, int e, int i)
 {
-    if constexpr (FLAVOR == kFlavorTjdsS)
+    if constexpr (FLAVOR == kFlavorTjdsS || FLAVOR == kFlavorTjdsH)
         return a.val[a.ovf_pos[ovf_base + i]] * a.x[a.ovf_k[ovf_base + i]];
     else
         return owner_product_slow<FLAVOR>(a, (long long)e + i);
@@ -271,8 +281,9 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     const OwnerArgs a = {col_ind, val, x, ex.pos, ex.start_pos, ex.ovf_pos, ex.ovf_k};
     constexpr int TILE = kStreamBlock * VPT;
     constexpr int QCAP = (TILE + kStreamOver) / kLongRow + 1;
-    constexpr bool TJDS = FLAVOR == kFlavorTjdsK || FLAVOR == kFlavorTjdsS;
-    constexpr bool SORTED = FLAVOR == kFlavorTjdsS;  // entries in TJDS order inside the tile, lane-strided
+    constexpr bool HALF = FLAVOR == kFlavorTjdsH;
+    constexpr bool TJDS = FLAVOR == kFlavorTjdsK || FLAVOR == kFlavorTjdsS || HALF;
+    constexpr bool SORTED = FLAVOR == kFlavorTjdsS || HALF;  // entries in TJDS order inside the tile, lane-strided
     static_assert(TILE <= (1 << kSlotBits), "slot bits");
     __shared__ double prod[TILE + kStreamOver];
     __shared__ int long_rows[QCAP];  // rows longer than kLongRow and their LDS segments, filled in phase 2b
@@ -317,7 +328,17 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     int pj[VPT];    // Tjds*: position in val
     double v[VPT];
     const bool full_tile = s + TILE <= (long long)nnz;
-    if constexpr (SORTED) {
+    int grp[HALF ? VPT : 1];  // TjdsH: run (inside the tile) of the first entry of this entry's group of 32
+    if constexpr (HALF) {
+        if (full_tile) {
+#pragma unroll
+            for (int k = 0; k < VPT; ++k) {
+                pj[k] = __builtin_nontemporal_load(a.pos + s + k * kStreamBlock + t);
+                c[k] = __builtin_nontemporal_load(ex.meta16 + s + k * kStreamBlock + t);  // slot | run hint << kSlotBits
+                grp[k] = ex.group_run[(size_t)b * (TILE / 32) + ((k * kStreamBlock + t) >> 5)];
+            }
+        }
+    } else if constexpr (SORTED) {
         if (full_tile) {
 #pragma unroll
             for (int k = 0; k < VPT; ++k) {
@@ -392,10 +413,18 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
         }
         if (full_tile) {
             int slot[VPT];
+            int run0 = 0;
+            if constexpr (HALF)
+                run0 = ex.run_ptr[b];
 #pragma unroll
             for (int k = 0; k < VPT; ++k) {
                 slot[k] = c[k] & ((1 << kSlotBits) - 1);
-                c[k] = pj[k] - a.start_pos[(unsigned)c[k] >> kSlotBits];
+                if constexpr (HALF) {
+                    const int r = grp[k] + (((c[k] >> kSlotBits) - grp[k]) & 31);
+                    c[k] = pj[k] - ex.run_sp[run0 + r];
+                } else {
+                    c[k] = pj[k] - a.start_pos[(unsigned)c[k] >> kSlotBits];
+                }
             }
             double xk[VPT];
             // the tile's last `cached` entries take their value from the tile's own run of the cache (coalesced) instead
@@ -419,9 +448,16 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
             for (int k = 0; k < VPT; ++k) {
                 const int idx = k * kStreamBlock + t;
                 if (s + idx < (long long)nnz) {
-                    const int pw = a.pos[s + idx], m = a.col_ind[s + idx];
+                    const int pw = a.pos[s + idx];
                     const double vv = idx < in_place ? a.val[pw] : ex.val_cache[cache0 + (idx - in_place)];
-                    prod[m & ((1 << kSlotBits) - 1)] = vv * a.x[pw - a.start_pos[(unsigned)m >> kSlotBits]];
+                    if constexpr (HALF) {
+                        const int m = ex.meta16[s + idx], g = ex.group_run[(size_t)b * (TILE / 32) + (idx >> 5)];
+                        const int r = g + (((m >> kSlotBits) - g) & 31);
+                        prod[m & ((1 << kSlotBits) - 1)] = vv * a.x[pw - ex.run_sp[ex.run_ptr[b] + r]];
+                    } else {
+                        const int m = a.col_ind[s + idx];
+                        prod[m & ((1 << kSlotBits) - 1)] = vv * a.x[pw - a.start_pos[(unsigned)m >> kSlotBits]];
+                    }
                 }
             }
             if (over0)
@@ -814,7 +850,7 @@ static unsigned owner_grid(int ntiles, int group) { return (unsigned)((ntiles + 
 // tiles per XCD turn by flavour: the tile-ordered TJDS stream re-uses val lines between neighbouring tiles and does
 // best when an XCD comes back to a neighbourhood soon (measured on memplus x944, 2048-entry tiles: group 16 / 32 /
 // 64 / 128 -> 0.592 / 0.596 / 0.612 / 0.601 ms); CSR measured best at 64 (profiles/r01_tile_group_sweep.txt)
-static int flavor_group(int flavor) { return flavor == kFlavorTjdsS ? kTjdsTileGroup : kStreamTileGroup; }
+static int flavor_group(int flavor) { return flavor == kFlavorTjdsS || flavor == kFlavorTjdsH ? kTjdsTileGroup : kStreamTileGroup; }
 
 int owner_stamp_slots(int ntiles, int flavor)
 {
@@ -836,6 +872,7 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
     OwnerExtra ex;
     ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_pos = l.ovf_pos, ex.ovf_k = l.ovf_k;
     ex.cache_ptr = l.cache_ptr, ex.val_cache = l.val_cache;
+    ex.meta16 = l.meta16, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_sp = l.run_sp;
     ex.stamps = l.stamps, ex.stream_nt = nt;
 #define SMVP_OWNER_ST(V, F, S)                                                                                     \
     hipLaunchKernelGGL((csr_stream_owner<V, F, S>), grid, dim3(kStreamBlock), 0, stream, l.row_ptr, l.col_ind, l.val, \
@@ -860,6 +897,9 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
     SMVP_OWNER(1, kFlavorTjdsS)
     SMVP_OWNER(4, kFlavorTjdsS)
     SMVP_OWNER(8, kFlavorTjdsS)
+    SMVP_OWNER(1, kFlavorTjdsH)
+    SMVP_OWNER(4, kFlavorTjdsH)
+    SMVP_OWNER(8, kFlavorTjdsH)
 #undef SMVP_OWNER
 #undef SMVP_OWNER_ST
     return hipErrorInvalidValue;

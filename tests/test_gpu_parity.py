@@ -229,10 +229,11 @@ def test_auto_plan_choice(torch):
 
 
 TJDS_MODES = [sm.TJDS_MODE_ROW_GATHER, sm.TJDS_MODE_TWO_PHASE, sm.TJDS_MODE_ATOMIC]
-# the one-kernel product: (index form of its stream, entries per tile); "sorted" = every tile in TJDS order (default)
-TJDS_GATHER_VARIANTS = [("sorted", 0), ("sorted", 256), ("sorted", 1024), ("sorted", 2048), ("k32", 256), ("k32", 1024),
-                        ("k32", 2048)]
-TJDS_FLAVORS = {"sorted": (3,), "k32": (2,)}
+# the one-kernel product: (index form of its stream, entries per tile); "half" = every tile in TJDS order, position + a
+# 16-bit slot | run-hint word per entry (default); "sorted" = the same order with a 32-bit slot | diagonal word; "k32" = row order
+TJDS_GATHER_VARIANTS = [("half", 0), ("half", 256), ("half", 1024), ("half", 2048), ("sorted", 0), ("sorted", 256),
+                        ("sorted", 1024), ("sorted", 2048), ("k32", 256), ("k32", 1024), ("k32", 2048)]
+TJDS_FLAVORS = {"half": (4,), "sorted": (3,), "k32": (2,)}
 
 
 def tjds_gather_matrix(t, index, tile):
@@ -257,13 +258,14 @@ def tjds_gather_matrix(t, index, tile):
 
 def test_tjds_value_cache_and_run_words_do_not_change_a_bit(torch):
     """The one-kernel product sums every row in ascending TJDS position whatever the plan keeps: values read from val or
-    from the tiles' cache (lines shared by >= 1, 2, 8, 16 tiles, or none), any tile size -- the same bits every time."""
+    from the tiles' cache (lines shared by >= 1, 2, 8, 16 tiles, or none), the second index word 32 or 16 bits wide, any tile
+    size -- the same bits every time."""
     for name in ("memplus.mtx", "pwt.mtx"):
         m, n, coo = load(name)
         t = sm.tjds_from_coo(coo, m, n)
         x = dev(torch, np.random.default_rng(3).random(n))
         want = None
-        for index in ("sorted",):
+        for index in ("sorted", "half"):
             for tile in (256, 2048):
                 T = tjds_gather_matrix(t, index, tile)
                 T.set_x(x)
@@ -279,6 +281,33 @@ def test_tjds_value_cache_and_run_words_do_not_change_a_bit(torch):
                     want = dy.clone() if want is None else want
                     assert torch.equal(dy, want), (name, index, tile, cache)
                 T.close()
+
+
+def test_tjds_half_words_with_a_run_per_entry(torch):
+    """A row whose 1000 entries each lie in another jagged diagonal: its tile's sorted entries form 1000 runs of one entry,
+    32 runs inside every group of 32 -- the most the 5-bit run hint has to tell apart."""
+    m, ncol = 1100, 1000
+    rows = np.concatenate([np.arange(j) for j in range(ncol)] + [np.full(ncol, m - 1)])       # column j: rows 0..j-1, then m-1
+    cols = np.concatenate([np.full(j, j) for j in range(ncol)] + [np.arange(ncol)])
+    rng = np.random.default_rng(12)
+    coo = sm.make_coo(rows, cols, rng.uniform(-1, 1, len(rows)))
+    t = sm.tjds_from_coo(coo, m, ncol)
+    assert t.num_diag == ncol
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    x = rng.random(ncol)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+    T = tjds_gather_matrix(t, "half", 0)
+    for tile in (256, 2048, 1024):
+        for cache in (4, 0, 1):
+            T.set_tile(tile)
+            T.set_value_cache(cache)
+            assert T.describe()[0] == "csr_stream_owner<%d, 4, false>" % (tile // 256)
+            dy = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+            T.set_x(dev(torch, x))
+            T.spmv(dy)
+            torch.cuda.synchronize()
+            assert_close(dy.cpu().numpy(), ref, row_scale(row_ptr, col_ind, val, x))
+    T.close()
 
 
 @pytest.mark.parametrize("name", SAMPLES)
@@ -714,15 +743,16 @@ def test_cli_dump_arrays_and_random_operand(torch, tmp_path):
     quiet = subprocess.run([sm.CLI_PATH, "-c", "-n", "1", "-d", str(tmp_path), path], capture_output=True, text=True).stdout
     assert "[DEBUG]" not in quiet
     # --x random
-    before = set(os.listdir(tmp_path))
-    r = subprocess.run([sm.CLI_PATH, "-c", "-t", "--x", "random", "-n", "2", "-d", str(tmp_path), path], capture_output=True, text=True)
+    sub = tmp_path / "random_x"              # its own folder: report names carry the second they were written in
+    sub.mkdir()
+    r = subprocess.run([sm.CLI_PATH, "-c", "-t", "--x", "random", "-n", "2", "-d", str(sub), path], capture_output=True, text=True)
     assert r.returncode == 0 and "Random vector" in r.stdout
     x = sm.vector_random(n, 67890)
     ref = ob.csr_spmv(row_ptr, col_ind, val, x)
-    new = sorted(set(os.listdir(tmp_path)) - before)
+    new = sorted(os.listdir(sub))
     assert len(new) == 2
     for f in new:
-        got = np.array([float(v) for v in ob.report_y_lines(open(tmp_path / f).read())])
+        got = np.array([float(v) for v in ob.report_y_lines(open(sub / f).read())])
         assert np.all(np.abs(got - ref) <= 1e-5 * row_scale(row_ptr, col_ind, val, x))
 
 
@@ -1125,7 +1155,7 @@ def test_bench_script_tjds_format(torch):
                        capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
     j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
-    assert j["config"]["format"] == "tjds" and "TJDS" in j["metric"] and j["roofline"]["kernel"] == "csr_stream_owner<4, 3, false>"
+    assert j["config"]["format"] == "tjds" and "TJDS" in j["metric"] and j["roofline"]["kernel"] == "csr_stream_owner<4, 4, false>"
     assert j["extra"]["full_size_parity"]["y_equals_tiled_reference_memplus_y"] and j["value"] > 0
     # roofline.traffic of this line was measured in the run itself (rocprofv3 --pmc child passes) unless rocprofv3 is
     # missing; either way it can only lie between the algorithmic bytes and a few times them

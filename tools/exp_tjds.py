@@ -2,7 +2,7 @@
 """Time the TJDS product forms (and the CSR product beside them) on HBM-sized workloads; check each against CSR.
 
     python3 tools/exp_tjds.py --workloads memplus_tiled,pwt_tiled,random,uniform --steps 20
-Variants: mode[:index[:tile[:cache]]]  with mode in two_phase | atomic | gather, index in sorted | k32, tile 256|1024|2048
+Variants: mode[:index[:tile[:cache]]]  with mode in two_phase | atomic | gather, index in sorted | half | k32, tile 256|1024|2048
 (0 = default), cache = tiles per val line from which on the values are cached (0 = none; default 8).
 """
 import argparse, os, sys, time
@@ -93,7 +93,7 @@ def main():
         for var in a.variants.split(","):
             parts = var.split(":")
             mode = modes[parts[0]]
-            os.environ["SMVP_TJDS_INDEX"] = parts[1] if len(parts) > 1 else "sorted"
+            os.environ["SMVP_TJDS_INDEX"] = parts[1] if len(parts) > 1 else "half"
             t0 = time.perf_counter()
             T = sm.TjdsMatrix(tj)          # default plan is built here ...
             T.set_mode(mode)               # ... and the variant's own one here
