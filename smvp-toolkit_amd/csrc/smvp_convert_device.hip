@@ -885,3 +885,80 @@ int build_colsweep_plan(const int *d_row_ptr, const int *d_col_ind, const double
 }
 
 }  // namespace smvp
+
+namespace {
+
+// smallest column of every tile of `tile` consecutive entries, and the widest span (largest - smallest) of any tile
+__global__ __launch_bounds__(256) void tile_column_spans(const int *__restrict__ col_ind, int nnz, int tile,
+                                                         int *__restrict__ col_base, int *__restrict__ widest)
+{
+    __shared__ int lo_s[4], hi_s[4];
+    const long long s = (long long)blockIdx.x * tile;
+    int lo = 0x7fffffff, hi = -1;
+    for (int i = threadIdx.x; i < tile && s + i < nnz; i += 256) {
+        const int c = col_ind[s + i];
+        lo = c < lo ? c : lo;
+        hi = c > hi ? c : hi;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int ol = __shfl_down(lo, off, 64), oh = __shfl_down(hi, off, 64);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        lo_s[threadIdx.x >> 6] = lo;
+        hi_s[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            lo = lo_s[w] < lo ? lo_s[w] : lo;
+            hi = hi_s[w] > hi ? hi_s[w] : hi;
+        }
+        col_base[blockIdx.x] = hi < 0 ? 0 : lo;
+        if (hi >= 0)
+            atomicMax(widest, hi - lo);
+    }
+}
+
+__global__ __launch_bounds__(256) void column_offsets(const int *__restrict__ col_ind, int nnz, int tile,
+                                                      const int *__restrict__ col_base, unsigned short *__restrict__ col16)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < nnz)
+        col16[j] = (unsigned short)(col_ind[j] - col_base[j / tile]);
+}
+
+}  // namespace
+
+namespace smvp {
+
+// kFlavorCsr16: col_ind a second time as 16-bit offsets from every tile's smallest column -- possible when no tile's
+// columns span 65536 or more (*fits; nothing is written to d_col16 otherwise).  d_col_base has one entry per tile.
+int build_column_offsets(const int *d_col_ind, int nnz, int tile, int *d_col_base, unsigned short *d_col16, int *fits,
+                         hipStream_t st)
+{
+    *fits = 0;
+    if (nnz <= 0)
+        return SMVP_OK;
+    const int ntiles = (int)(((long long)nnz + tile - 1) / tile);
+    Scratch sc;
+    int *widest;
+    HIP_TRY(sc.get(&widest, 1));
+    HIP_TRY(hipMemsetAsync(widest, 0, sizeof(int), st));
+    hipLaunchKernelGGL(tile_column_spans, dim3((unsigned)ntiles), dim3(256), 0, st, d_col_ind, nnz, tile, d_col_base, widest);
+    HIP_TRY(hipGetLastError());
+    int h_widest = 0;
+    HIP_TRY(hipMemcpyAsync(&h_widest, widest, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h_widest >= 65536)
+        return SMVP_OK;
+    hipLaunchKernelGGL(column_offsets, dim3(blocks_for(nnz)), dim3(256), 0, st, d_col_ind, nnz, tile, d_col_base, d_col16);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    *fits = 1;
+    return SMVP_OK;
+}
+
+}  // namespace smvp

@@ -31,6 +31,7 @@ constexpr int kFlavorTjdsK = 2;  // val[pos[j]] * x_perm[col_ind[j]]   (col_ind 
 constexpr int kFlavorTjdsS = 3;  // the same entries, every tile's in TJDS order; col_ind = LDS slot | diagonal << kSlotBits
 constexpr int kFlavorTjdsH = 4;  // kFlavorTjdsS with a 16-bit second word: slot | run hint << 11; the start_pos of the entry's
                                  // diagonal comes from the tile's run table (6 bytes of index per entry instead of 8)
+constexpr int kFlavorCsr16 = 5;  // kFlavorCsr reading 16-bit column offsets: x[col_base[tile] + col16[j]] (tiles whose columns span < 65536)
 constexpr int kSlotBits = 11;    // a tile holds at most 2048 entries
 
 struct OwnerLaunch {
@@ -44,6 +45,8 @@ struct OwnerLaunch {
     const int *ovf_ptr = nullptr, *ovf_pos = nullptr, *ovf_k = nullptr;  // kFlavorTjdsS
     const int *cache_ptr = nullptr;                                      // kFlavorTjdsS
     const double *val_cache = nullptr;
+    const unsigned short *col16 = nullptr;                               // kFlavorCsr16
+    const int *col_base = nullptr;
     const unsigned short *meta16 = nullptr, *group_run = nullptr;        // kFlavorTjdsH
     const int *run_ptr = nullptr, *run_sp = nullptr;
     int rows = 0, nnz = 0, ntiles = 0;

@@ -199,6 +199,10 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_tiles(
 //
 // FLAVOR selects what an "entry" is (owner_entry below):
 //   kFlavorCsr     CSR: value val[j], operand x[col_ind[j]]                       (main-cli.c:410-416)
+//   kFlavorCsr16   the same product with 10 instead of 12 bytes per entry: where every tile's columns span less than 65536
+//                  (banded and block-structured matrices) the plan keeps col_ind a second time as 16-bit offsets from the
+//                  tile's smallest column; the tile adds its base (one scalar) back.  Overflow entries and the slow paths
+//                  read col_ind itself.
 //   kFlavorUnit    every value 1 (val not read): y[r] = sum x[col_ind[j]]; second phase of the two-phase TJDS product
 //   kFlavorTjdsK   TJDS by rows: the stream lists, row by row, the TJDS positions p of the row's entries (`pos`) and
 //                  their permuted columns k (`col_ind`): value val[p] gathered from the jagged-diagonal array,
@@ -227,6 +231,8 @@ struct OwnerExtra {
     const int *ovf_k;               // TjdsS: ... and permuted column of the entries [e, tile_next) of each tile, row order
     const int *cache_ptr;           // TjdsS: ntiles + 1 bounds of the tiles' runs in val_cache (a tile's last entries)
     const double *val_cache;        // TjdsS: values of the entries whose val lines scatter over many tiles, tile by tile
+    const unsigned short *col16;    // Csr16: column - col_base[tile] per entry
+    const int *col_base;            // Csr16: smallest column of every tile
     const unsigned short *meta16;   // TjdsH: slot | run hint << kSlotBits per entry
     const unsigned short *group_run;  // TjdsH: per tile and group of 32 entries, the run (inside the tile) of its first entry
     const int *run_ptr;             // TjdsH: ntiles + 1 bounds of the tiles' runs in run_sp
@@ -250,7 +256,7 @@ struct OwnerArgs {
 template <int FLAVOR>
 __device__ __forceinline__ double owner_product_slow(const OwnerArgs &a, long long j)
 {
-    if constexpr (FLAVOR == kFlavorCsr)
+    if constexpr (FLAVOR == kFlavorCsr || FLAVOR == kFlavorCsr16)
         return a.val[j] * a.x[a.col_ind[j]];
     else if constexpr (FLAVOR == kFlavorUnit)
         return a.x[a.col_ind[j]];
@@ -281,6 +287,8 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     const OwnerArgs a = {col_ind, val, x, ex.pos, ex.start_pos, ex.ovf_pos, ex.ovf_k};
     constexpr int TILE = kStreamBlock * VPT;
     constexpr int QCAP = (TILE + kStreamOver) / kLongRow + 1;
+    constexpr bool CSR = FLAVOR == kFlavorCsr || FLAVOR == kFlavorCsr16;
+    constexpr bool COL16 = FLAVOR == kFlavorCsr16;
     constexpr bool HALF = FLAVOR == kFlavorTjdsH;
     constexpr bool TJDS = FLAVOR == kFlavorTjdsK || FLAVOR == kFlavorTjdsS || HALF;
     constexpr bool SORTED = FLAVOR == kFlavorTjdsS || HALF;  // entries in TJDS order inside the tile, lane-strided
@@ -353,9 +361,19 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
         }
     } else if (whole) {
         if constexpr (VPT >= 4) {
+            if constexpr (COL16) {
+                const int base = ex.col_base[b];
 #pragma unroll
-            for (int k = 0; k < VPT; k += 4)
-                *reinterpret_cast<int4 *>(&c[k]) = *reinterpret_cast<const int4 *>(a.col_ind + j0 + k);
+                for (int k = 0; k < VPT; k += 4) {  // four 16-bit offsets per 8-byte load
+                    const uint2 w = *reinterpret_cast<const uint2 *>(ex.col16 + j0 + k);
+                    c[k] = base + (int)(w.x & 0xffffu), c[k + 1] = base + (int)(w.x >> 16);
+                    c[k + 2] = base + (int)(w.y & 0xffffu), c[k + 3] = base + (int)(w.y >> 16);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < VPT; k += 4)
+                    *reinterpret_cast<int4 *>(&c[k]) = *reinterpret_cast<const int4 *>(a.col_ind + j0 + k);
+            }
             if constexpr (TJDS) {
                 if (ex.stream_nt) {
 #pragma unroll
@@ -367,7 +385,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
                         *reinterpret_cast<int4 *>(&pj[k]) = *reinterpret_cast<const int4 *>(a.pos + j0 + k);
                 }
             }
-            if constexpr (FLAVOR == kFlavorCsr) {
+            if constexpr (CSR) {
 #pragma unroll
                 for (int k = 0; k < VPT; k += 2)
                     *reinterpret_cast<double2 *>(&v[k]) = *reinterpret_cast<const double2 *>(a.val + j0 + k);
@@ -376,7 +394,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
             c[0] = a.col_ind[j0];
             if constexpr (TJDS)
                 pj[0] = a.pos[j0];
-            if constexpr (FLAVOR == kFlavorCsr)
+            if constexpr (CSR)
                 v[0] = a.val[j0];
         }
     }
@@ -474,7 +492,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
             co = a.col_ind[e + t];
             if constexpr (TJDS)
                 pjo = a.pos[e + t];
-            if constexpr (FLAVOR == kFlavorCsr)
+            if constexpr (CSR)
                 vo = a.val[e + t];
         }
         double xk[VPT];
@@ -872,6 +890,7 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
     OwnerExtra ex;
     ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_pos = l.ovf_pos, ex.ovf_k = l.ovf_k;
     ex.cache_ptr = l.cache_ptr, ex.val_cache = l.val_cache;
+    ex.col16 = l.col16, ex.col_base = l.col_base;
     ex.meta16 = l.meta16, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_sp = l.run_sp;
     ex.stamps = l.stamps, ex.stream_nt = nt;
 #define SMVP_OWNER_ST(V, F, S)                                                                                     \
@@ -888,6 +907,8 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
     SMVP_OWNER(1, kFlavorCsr)
     SMVP_OWNER(4, kFlavorCsr)
     SMVP_OWNER(8, kFlavorCsr)
+    SMVP_OWNER(4, kFlavorCsr16)
+    SMVP_OWNER(8, kFlavorCsr16)
     SMVP_OWNER(1, kFlavorUnit)
     SMVP_OWNER(4, kFlavorUnit)
     SMVP_OWNER(8, kFlavorUnit)

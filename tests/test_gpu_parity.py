@@ -138,6 +138,55 @@ def test_stream_kernel_is_bitwise_serial_on_short_rows(torch):
         assert np.array_equal(y[one_tile], ref[one_tile])
 
 
+def test_csr_16_bit_column_offsets(torch):
+    """Where every tile's columns span less than 65536 the tile kernel reads 16-bit offsets from the tile's smallest column
+    (csr_stream_owner<., 5, .>: 10 instead of 12 bytes per entry); a single wider tile keeps the whole matrix on col_ind
+    itself (<., 0, .>).  Same bits either way, and as the serial loop on rows of up to 32 entries."""
+    rng = np.random.default_rng(21)
+    rows = 3000
+    for width, flavor in ((65535, 5), (65536, 0)):
+        lens = rng.integers(2, 9, rows)
+        row_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        col_ind = np.concatenate([np.sort(rng.choice(2000, size=n, replace=False)) for n in lens]).astype(np.int32)
+        j = int(row_ptr[1500])
+        col_ind[j], col_ind[j + lens[1500] - 1] = 0, width            # one row from column 0 to column `width`: its tile's span
+        cols = int(col_ind.max()) + 1
+        val = rng.uniform(-1, 1, len(col_ind))
+        x = rng.random(cols)
+        ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+        A = sm.CsrMatrix(rows, cols, row_ptr, col_ind, val)
+        dx = dev(torch, x)
+        for tile in (1024, 2048):
+            A.set_kernel(sm.CSR_KERNEL_STREAM, tile)
+            assert A.describe()[0] == "csr_stream_owner<%d, %d, false>" % (tile // 256, flavor)
+            dy = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+            A.spmv(dx, dy)
+            torch.cuda.synchronize()
+            assert np.array_equal(dy.cpu().numpy(), ref)
+        A.set_kernel(sm.CSR_KERNEL_STREAM, 256)                     # 256-entry tiles always read col_ind
+        assert A.describe()[0] == "csr_stream_owner<1, 0, false>"
+        A.close()
+    # the development switch: same bits without the offsets
+    m, n, coo = load("memplus.mtx")
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    x = rng.random(n)
+    got = []
+    for env in ("1", "0"):
+        os.environ["SMVP_CSR_COL16"] = env
+        try:
+            A = sm.CsrMatrix(m, n, row_ptr, col_ind, val)
+            A.set_kernel(sm.CSR_KERNEL_STREAM, 1024)
+            assert A.describe()[0] == "csr_stream_owner<4, %d, false>" % (5 if env == "1" else 0)
+            dy = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+            A.spmv(dev(torch, x), dy)
+            torch.cuda.synchronize()
+            got.append(dy.cpu().numpy())
+            A.close()
+        finally:
+            del os.environ["SMVP_CSR_COL16"]
+    assert np.array_equal(got[0], got[1])
+
+
 def test_colsweep_on_scattered_columns(torch):
     """The column-swept kernel on a config-4-shaped matrix (uniform columns over an operand larger than L2): AUTO picks
     it from its create-time estimate of the gather spread; every row is summed in ascending column order, so the result

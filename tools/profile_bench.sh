@@ -10,7 +10,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p "$OUT"
 ARGS="--no-live-traffic --no-c-layer --no-random-model --no-tjds --no-cpu-baseline --no-samples --no-config4 --no-pwt-tiled ${BENCH_ARGS:-}"
-PAT=${PAT:-csr_stream_owner<4, 0}   # kernel-name substring the PMC summary is taken over
+PAT=${PAT:-csr_stream_owner<8, 5}   # kernel-name substring the PMC summary is taken over
 python3 $R/bench.py --steps 100 --warmup 10 $ARGS > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "bench failed"; tail -5 "$OUT/bench.err"; exit 1; }
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 $R/bench.py --steps 100 --warmup 10 $ARGS > "$OUT/trace.log" 2>&1 || echo "kernel-trace pass failed"
