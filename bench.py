@@ -661,7 +661,9 @@ def roofline_of(res, workload=None):
          "alg_bytes_per_launch": res["alg_bytes_local"] / res.get("launches", 1),
          "ms_per_launch": round(res["kernel_ms"] / res.get("launches", 1), 5), "launches_per_product": res.get("launches", 1),
          "note": "HIP events on the launch stream over the timed products; one launch per product except the column "
-                 "sweep's generations"}
+                 "sweep's generations" +
+                 ("; this kernel reads the plan's 16-bit column offsets (2 B per entry) where the algorithmic count has "
+                  "col_ind's 4 B, so the measured traffic can lie below the algorithmic bytes" if ", 5, " in res["kernel"] else "")}
     rec = recorded_traffic(workload, res["kernel"], res["alg_bytes_local"]) if workload else None
     if rec:
         r["traffic"] = rec[0]
