@@ -185,6 +185,17 @@ def test_csr_16_bit_column_offsets(torch):
         finally:
             del os.environ["SMVP_CSR_COL16"]
     assert np.array_equal(got[0], got[1])
+    # and through the reference-shaped entry point with the kernel timing itself (the STAMPED instantiation of <4, 5, .>)
+    n = 300_000
+    band = np.clip(np.arange(n, dtype=np.int64)[:, None] + np.arange(-3, 4), 0, n - 1).astype(np.int32)   # no wrap: every tile is narrow
+    vals = rng.uniform(-1, 1, band.size)
+    coo = sm.make_coo(np.repeat(np.arange(n), 7), band.ravel(), vals)
+    A = sm.CsrMatrix(n, n, (np.arange(n + 1, dtype=np.int64) * 7).astype(np.int32), band.ravel(), vals)
+    assert A.describe()[0] == "csr_stream_owner<4, 5, false>"
+    A.close()
+    y, ms, st = sm.csr_compute(coo, n, n, iters=5, timing=sm.TIMING_DEVICE)
+    assert sm.last_run_info().timing == sm.TIMING_DEVICE and 0 < st.time_min < 1.0
+    assert np.array_equal(y, ob.csr_spmv((np.arange(n + 1, dtype=np.int64) * 7).astype(np.int32), band.ravel(), vals, np.ones(n)))
 
 
 def test_colsweep_on_scattered_columns(torch):
