@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -577,7 +578,11 @@ extern "C" int smvp_sharded_spmv(smvp_sharded_t *h, int allgather, int timed)
     if (!h || allgather < 0 || allgather > SMVP_GATHER_AFTER)
         return smvp::fail(SMVP_ERR_INVALID, "smvp_sharded_spmv: bad argument");
     const size_t n = (size_t)h->n;
-    if (n == 1) {
+    static const bool always_threads = [] {
+        const char *e = getenv("SMVP_SHARDED_THREADS");  // development switch: the issuing threads with one GPU too
+        return e && atoi(e) != 0;
+    }();
+    if (n == 1 && !always_threads) {
         DeviceScope keep;
         return issue_product(h, 0, allgather, timed);
     }

@@ -1108,6 +1108,44 @@ def test_sharded_unequal_blocks_on_several_gpus(torch, ngpus):
             assert np.array_equal(got[sm.GATHER_OVERLAPPED], got[sm.GATHER_AFTER])    # the same bits either way
 
 
+def test_sharded_issuing_thread_machinery_on_one_gpu(torch, tmp_path):
+    """With several GPUs every GPU's launches and collectives are issued by its own thread (woken per product, joined at
+    destroy).  SMVP_SHARDED_THREADS=1 runs that machinery with the one GPU of this box: many products, both exchange
+    forms, power iteration, an early destroy -- same results as the caller's-thread path."""
+    import sys
+
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import smvp_toolkit_amd as sm, oracle_binding as ob
+tc, m, n, coo = sm.mm_read_coo(ob.fixture_path("memplus.mtx"))
+rp, ci, v = sm.csr_from_coo(coo, m)
+ref = ob.csr_spmv(rp, ci, v, np.ones(n))
+for fmt in ("csr", "tjds"):
+    S = sm.ShardedMatrix(fmt, 1, m, n, coo=coo, csr=(rp, ci, v), chunks=4)
+    S.set_x(None)
+    for it in range(200):
+        S.spmv(allgather=(sm.GATHER_OVERLAPPED, sm.GATHER_AFTER, sm.GATHER_NONE)[it %% 3])
+        if it %% 50 == 0:
+            S.synchronize()
+    S.spmv(allgather=sm.GATHER_OVERLAPPED)
+    ms = S.synchronize()
+    y = S.get_y(0, gathered=True)
+    assert ms > 0 and np.allclose(y, ref, rtol=1e-12, atol=1e-12), fmt
+    S.feed_back(normalize=True)
+    S.spmv()
+    S.close()
+S = sm.ShardedMatrix("csr", 1, m, n, csr=(rp, ci, v), chunks=2)       # destroyed without a product: no thread was started
+S.close()
+y, ms, st = sm.csr_compute(coo, m, n, iters=20)
+assert np.allclose(y, ref, rtol=1e-12, atol=1e-12)
+print("threads ok")
+""" % (os.path.join(os.path.dirname(sm.LIB_PATH), "..", "python"), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMVP_SHARDED_THREADS="1")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0 and "threads ok" in p.stdout, p.stdout + p.stderr
+
+
 def test_device_timing_is_refused_for_a_sharded_run(torch):
     """The in-kernel stamps time one launch on one GPU; a sharded product is several launches on several GPUs: asking for
     them is an error, not silently something else (the check comes before any GPU is opened)."""
