@@ -175,8 +175,8 @@ void free_sweep_plan(smvp_csr *h)
 // 1024 * cols / (rb * mean) columns of x per pass: the taller the block, the slower the window and the better the
 // XCD's L2 holds what the resident workgroups gather -- but the launch should still have a few hundred workgroups.
 // So: the tallest of 8192 / 4096 / 2048 / 1024 rows (8192 rows = 64 KB of sums in LDS) that leaves >= 128 workgroups,
-// but never so short that a pass moves the window by more than ~1.3 MB.  All workgroups start together when they are
-// resident at once, else in even generations of at most 256.  Measured on BASELINE config 4 (round 3, deterministic
+// but never so short that a pass moves the window by more than ~1.3 MB.  The workgroups start in even generations of at
+// most 256, one per CU.  Measured on BASELINE config 4 (round 3, deterministic
 // kernel, tools/exp_colsweep.py): 10 M rows -> 8192 / 5 x 245: 2.25 ms (4096: 2.62); one rank's eighth, 1.25 M rows ->
 // 8192 / all 153: 0.44 ms (4096: 0.48); a 312 K-row chunk -> 2048 / all 153: 0.134 ms (1024: 0.169, 4096: 0.25).
 void choose_sweep_shape(int rows, int cols, int nnz, int want_rb, int *rb, int *per_launch)
@@ -193,7 +193,9 @@ void choose_sweep_shape(int rows, int cols, int nnz, int want_rb, int *rb, int *
         r = want_rb;
     const int nrb = (rows + r - 1) / r;
     *rb = r;
-    *per_launch = nrb <= 640 ? nrb : (nrb + ((nrb + 255) / 256) - 1) / ((nrb + 255) / 256);
+    // generations of at most 256 workgroups, one per CU, of equal size (2.5 M rows, 305 workgroups: 2 x 153 0.883 ms, all at once
+    // 0.926; 5 M rows: 3 x 204 1.331 against 1.540 -- the workgroups that start late drift out of the others' window)
+    *per_launch = (nrb + ((nrb + 255) / 256) - 1) / ((nrb + 255) / 256);
 }
 
 int build_sweep_plan(smvp_csr *h, int want_rb)
