@@ -173,29 +173,38 @@ void free_sweep_plan(smvp_csr *h)
 // Rows per workgroup of the column sweep (four strips) and how many workgroups start together.  A block of rb rows streams
 // rb * (mean row length) entries in column order, 1024 per pass of its workgroup (256 per strip), so its window moves
 // 1024 * cols / (rb * mean) columns of x per pass: the taller the block, the slower the window and the better the
-// XCD's L2 holds what the resident workgroups gather -- but the launch should still have a few hundred workgroups.
-// So: the tallest of 8192 / 4096 / 2048 / 1024 rows (8192 rows = 64 KB of sums in LDS) that leaves >= 128 workgroups,
-// but never so short that a pass moves the window by more than ~1.3 MB.  The workgroups start in even generations of at
-// most 256, one per CU.  Measured on BASELINE config 4 (round 3, deterministic
-// kernel, tools/exp_colsweep.py): 10 M rows -> 8192 / 5 x 245: 2.25 ms (4096: 2.62); one rank's eighth, 1.25 M rows ->
-// 8192 / all 153: 0.44 ms (4096: 0.48); a 312 K-row chunk -> 2048 / all 153: 0.134 ms (1024: 0.169, 4096: 0.25).
+// XCD's L2 holds what the resident workgroups gather.  The workgroups start in even generations of at most 256, one per
+// CU -- those that start late drift out of the others' window (2.5 M rows, 305 workgroups: 2 x 153 0.883 ms, all at once
+// 0.926; 5 M rows: 3 x 204 1.331 against 1.540) -- so a height also decides how full the chip is: 1.25 M rows as 153
+// workgroups of 8192 rows keep 60 % of the CUs busy (0.439 ms), as 3 x 204 of 2048 rows 80 % (0.411 ms).  Measured at equal
+// fill, 8192 rows run at 1.0, 4096 at 0.86, 2048 at 0.80 of the rate (config 4: 2.25 / 2.62 ms); the height is the one with
+// the best fill x rate, never so short that a pass moves the window by more than ~1.3 MB (tools/exp_colsweep.py,
+// profiles/r03_colsweep_measured.txt).
 void choose_sweep_shape(int rows, int cols, int nnz, int want_rb, int *rb, int *per_launch)
 {
-    int r = 8192;
-    while (r > 1024 && (rows + r - 1) / r < 128)
-        r >>= 1;
     const double mean = rows > 0 ? std::max(1.0, (double)nnz / rows) : 1.0;
     int floor_rb = 1024;
     while (floor_rb < 8192 && (double)floor_rb * mean * 160.0 < (double)cols)
         floor_rb <<= 1;
-    r = std::max(r, floor_rb);
+    auto generations = [](int nrb) { return (nrb + 255) / 256; };
+    int r = floor_rb;
+    double best = -1.0;
+    const struct { int rows; double rate; } heights[] = {{8192, 1.0}, {4096, 0.86}, {2048, 0.80}, {1024, 0.70}};
+    for (const auto &hgt : heights) {
+        if (hgt.rows < floor_rb)
+            continue;
+        const int nrb = (rows + hgt.rows - 1) / hgt.rows;
+        const double fill = (double)nrb / (generations(nrb) * 256.0);
+        if (fill * hgt.rate > best) {
+            best = fill * hgt.rate;
+            r = hgt.rows;
+        }
+    }
     if (want_rb > 0)
         r = want_rb;
     const int nrb = (rows + r - 1) / r;
     *rb = r;
-    // generations of at most 256 workgroups, one per CU, of equal size (2.5 M rows, 305 workgroups: 2 x 153 0.883 ms, all at once
-    // 0.926; 5 M rows: 3 x 204 1.331 against 1.540 -- the workgroups that start late drift out of the others' window)
-    *per_launch = (nrb + ((nrb + 255) / 256) - 1) / ((nrb + 255) / 256);
+    *per_launch = (nrb + generations(nrb) - 1) / generations(nrb);
 }
 
 int build_sweep_plan(smvp_csr *h, int want_rb)

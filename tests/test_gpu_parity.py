@@ -207,7 +207,7 @@ def test_colsweep_on_scattered_columns(torch):
     x = np.random.default_rng(9).random(cols)
     ref = ob.csr_spmv(row_ptr, col_ind, val, x)
     A = sm.CsrMatrix(rows, cols, row_ptr, col_ind, val)
-    assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, 4096)      # 700 K rows: 4096 per workgroup leaves >= 128 (171)
+    assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, 1024)      # 700 K rows: 684 workgroups of 1024 rows = 3 generations of 228
     dx = dev(torch, x)
     dy = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
     A.spmv(dx, dy)
@@ -218,7 +218,7 @@ def test_colsweep_on_scattered_columns(torch):
     A.spmv(dx, dy)
     torch.cuda.synchronize()
     assert np.array_equal(dy.cpu().numpy(), ref)                  # 32 entries per row: the tile kernel is serial too
-    for rb, want in ((0, 4096), (8192, 8192), (2048, 2048), (1024, 1024)):
+    for rb, want in ((0, 1024), (8192, 8192), (2048, 2048), (4096, 4096)):
         A.set_kernel(sm.CSR_KERNEL_COLSWEEP, rb)
         assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, want) and A.describe()[0].startswith("csr_colsweep<")
         for _ in range(2):
@@ -229,7 +229,7 @@ def test_colsweep_on_scattered_columns(torch):
     with pytest.raises(sm.SmvpError):
         A.set_kernel(sm.CSR_KERNEL_COLSWEEP, 3000)
     A.set_kernel(sm.CSR_KERNEL_AUTO, 0)                       # AUTO again: the sweep, plan rebuilt
-    assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, 4096)
+    assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, 1024)
     dy.fill_(float("nan"))
     A.spmv(dx, dy)
     torch.cuda.synchronize()
