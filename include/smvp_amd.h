@@ -159,8 +159,8 @@ enum {
     SMVP_CSR_KERNEL_AUTO = 0,
     SMVP_CSR_KERNEL_VECTOR = 1,      /* one (sub-)wavefront per row, __shfl_down sums */
     SMVP_CSR_KERNEL_STREAM = 2,      /* fixed-nnz tiles, LDS-staged segmented reduction; a row is finished by
-                                        the tile it starts in (one launch).  Where no tile's columns span 65536 or
-                                        more the plan keeps col_ind a second time as 16-bit offsets from the tile's
+                                        the tile it starts in (one launch).  For the tiles whose columns span less than 65536 (if
+                                        most are such) the plan keeps col_ind a second time as 16-bit offsets from the tile's
                                         smallest column and the product reads those (same sums, fewer bytes) */
     SMVP_CSR_KERNEL_STREAM_CARRY = 3, /* same tiles; a row that crosses tiles is combined from per-tile carries
                                          by a second small launch (for matrices with extremely long rows) */

@@ -888,9 +888,10 @@ int build_colsweep_plan(const int *d_row_ptr, const int *d_col_ind, const double
 
 namespace {
 
-// smallest column of every tile of `tile` consecutive entries, and the widest span (largest - smallest) of any tile
+// smallest column of every tile of `tile` consecutive entries whose columns span (largest - smallest) less than 65536,
+// -1 for the wider tiles; *narrow = how many tiles are of the first kind
 __global__ __launch_bounds__(256) void tile_column_spans(const int *__restrict__ col_ind, int nnz, int tile,
-                                                         int *__restrict__ col_base, int *__restrict__ widest)
+                                                         int *__restrict__ col_base, int *__restrict__ narrow)
 {
     __shared__ int lo_s[4], hi_s[4];
     const long long s = (long long)blockIdx.x * tile;
@@ -916,9 +917,10 @@ __global__ __launch_bounds__(256) void tile_column_spans(const int *__restrict__
             lo = lo_s[w] < lo ? lo_s[w] : lo;
             hi = hi_s[w] > hi ? hi_s[w] : hi;
         }
-        col_base[blockIdx.x] = hi < 0 ? 0 : lo;
-        if (hi >= 0)
-            atomicMax(widest, hi - lo);
+        const bool fits = hi < 0 || hi - lo < 65536;
+        col_base[blockIdx.x] = !fits ? -1 : (hi < 0 ? 0 : lo);
+        if (fits)
+            atomicAdd(narrow, 1);
     }
 }
 
@@ -926,16 +928,19 @@ __global__ __launch_bounds__(256) void column_offsets(const int *__restrict__ co
                                                       const int *__restrict__ col_base, unsigned short *__restrict__ col16)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j < nnz)
-        col16[j] = (unsigned short)(col_ind[j] - col_base[j / tile]);
+    if (j < nnz) {
+        const int base = col_base[j / tile];
+        col16[j] = base < 0 ? (unsigned short)0 : (unsigned short)(col_ind[j] - base);  // a wide tile reads col_ind itself
+    }
 }
 
 }  // namespace
 
 namespace smvp {
 
-// kFlavorCsr16: col_ind a second time as 16-bit offsets from every tile's smallest column -- possible when no tile's
-// columns span 65536 or more (*fits; nothing is written to d_col16 otherwise).  d_col_base has one entry per tile.
+// kFlavorCsr16: col_ind a second time as 16-bit offsets from every tile's smallest column, for the tiles whose columns span
+// less than 65536 (d_col_base[tile] = -1 marks the others: they read col_ind itself).  *fits when at least half of the
+// tiles are of the narrow kind (nothing is written to d_col16 otherwise).  d_col_base has one entry per tile.
 int build_column_offsets(const int *d_col_ind, int nnz, int tile, int *d_col_base, unsigned short *d_col16, int *fits,
                          hipStream_t st)
 {
@@ -944,15 +949,15 @@ int build_column_offsets(const int *d_col_ind, int nnz, int tile, int *d_col_bas
         return SMVP_OK;
     const int ntiles = (int)(((long long)nnz + tile - 1) / tile);
     Scratch sc;
-    int *widest;
-    HIP_TRY(sc.get(&widest, 1));
-    HIP_TRY(hipMemsetAsync(widest, 0, sizeof(int), st));
-    hipLaunchKernelGGL(tile_column_spans, dim3((unsigned)ntiles), dim3(256), 0, st, d_col_ind, nnz, tile, d_col_base, widest);
+    int *narrow;
+    HIP_TRY(sc.get(&narrow, 1));
+    HIP_TRY(hipMemsetAsync(narrow, 0, sizeof(int), st));
+    hipLaunchKernelGGL(tile_column_spans, dim3((unsigned)ntiles), dim3(256), 0, st, d_col_ind, nnz, tile, d_col_base, narrow);
     HIP_TRY(hipGetLastError());
-    int h_widest = 0;
-    HIP_TRY(hipMemcpyAsync(&h_widest, widest, sizeof(int), hipMemcpyDeviceToHost, st));
+    int h_narrow = 0;
+    HIP_TRY(hipMemcpyAsync(&h_narrow, narrow, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (h_widest >= 65536)
+    if (2 * (long long)h_narrow < (long long)ntiles)
         return SMVP_OK;
     hipLaunchKernelGGL(column_offsets, dim3(blocks_for(nnz)), dim3(256), 0, st, d_col_ind, nnz, tile, d_col_base, d_col16);
     HIP_TRY(hipGetLastError());

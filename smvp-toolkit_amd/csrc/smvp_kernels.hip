@@ -199,10 +199,10 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_tiles(
 //
 // FLAVOR selects what an "entry" is (owner_entry below):
 //   kFlavorCsr     CSR: value val[j], operand x[col_ind[j]]                       (main-cli.c:410-416)
-//   kFlavorCsr16   the same product with 10 instead of 12 bytes per entry: where every tile's columns span less than 65536
-//                  (banded and block-structured matrices) the plan keeps col_ind a second time as 16-bit offsets from the
-//                  tile's smallest column; the tile adds its base (one scalar) back.  Overflow entries and the slow paths
-//                  read col_ind itself.
+//   kFlavorCsr16   the same product with 10 instead of 12 bytes per entry: for the tiles whose columns span less than 65536
+//                  (banded and block-structured matrices: all of them) the plan keeps col_ind a second time as 16-bit
+//                  offsets from the tile's smallest column; the tile adds its base (one scalar) back.  Wider tiles
+//                  (col_base < 0), overflow entries and the slow paths read col_ind itself.
 //   kFlavorUnit    every value 1 (val not read): y[r] = sum x[col_ind[j]]; second phase of the two-phase TJDS product
 //   kFlavorTjdsK   TJDS by rows: the stream lists, row by row, the TJDS positions p of the row's entries (`pos`) and
 //                  their permuted columns k (`col_ind`): value val[p] gathered from the jagged-diagonal array,
@@ -363,11 +363,17 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
         if constexpr (VPT >= 4) {
             if constexpr (COL16) {
                 const int base = ex.col_base[b];
+                if (base >= 0) {
 #pragma unroll
-                for (int k = 0; k < VPT; k += 4) {  // four 16-bit offsets per 8-byte load
-                    const uint2 w = *reinterpret_cast<const uint2 *>(ex.col16 + j0 + k);
-                    c[k] = base + (int)(w.x & 0xffffu), c[k + 1] = base + (int)(w.x >> 16);
-                    c[k + 2] = base + (int)(w.y & 0xffffu), c[k + 3] = base + (int)(w.y >> 16);
+                    for (int k = 0; k < VPT; k += 4) {  // four 16-bit offsets per 8-byte load
+                        const uint2 w = *reinterpret_cast<const uint2 *>(ex.col16 + j0 + k);
+                        c[k] = base + (int)(w.x & 0xffffu), c[k + 1] = base + (int)(w.x >> 16);
+                        c[k + 2] = base + (int)(w.y & 0xffffu), c[k + 3] = base + (int)(w.y >> 16);
+                    }
+                } else {  // a tile whose columns span 65536 or more
+#pragma unroll
+                    for (int k = 0; k < VPT; k += 4)
+                        *reinterpret_cast<int4 *>(&c[k]) = *reinterpret_cast<const int4 *>(a.col_ind + j0 + k);
                 }
             } else {
 #pragma unroll

@@ -139,17 +139,19 @@ def test_stream_kernel_is_bitwise_serial_on_short_rows(torch):
 
 
 def test_csr_16_bit_column_offsets(torch):
-    """Where every tile's columns span less than 65536 the tile kernel reads 16-bit offsets from the tile's smallest column
-    (csr_stream_owner<., 5, .>: 10 instead of 12 bytes per entry); a single wider tile keeps the whole matrix on col_ind
-    itself (<., 0, .>).  Same bits either way, and as the serial loop on rows of up to 32 entries."""
+    """A tile whose columns span less than 65536 reads 16-bit offsets from its smallest column (csr_stream_owner<., 5, .>:
+    10 instead of 12 bytes per entry); a wider tile of the same matrix reads col_ind itself; a matrix in which most tiles
+    are wide keeps the plain kernel (<., 0, .>).  Same bits every way, and as the serial loop on rows of up to 32 entries."""
     rng = np.random.default_rng(21)
     rows = 3000
-    for width, flavor in ((65535, 5), (65536, 0)):
+    for wide_rows, width, flavor in (([1500], 65535, 5), ([1500], 65536, 5), ([7, 1500, 2990], 3_000_000, 5),
+                                     (range(rows), 65536, 0)):
         lens = rng.integers(2, 9, rows)
         row_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
         col_ind = np.concatenate([np.sort(rng.choice(2000, size=n, replace=False)) for n in lens]).astype(np.int32)
-        j = int(row_ptr[1500])
-        col_ind[j], col_ind[j + lens[1500] - 1] = 0, width            # one row from column 0 to column `width`: its tile's span
+        for r in wide_rows:                                            # rows from column 0 to column `width`: their tiles' span
+            j = int(row_ptr[r])
+            col_ind[j], col_ind[j + lens[r] - 1] = 0, width
         cols = int(col_ind.max()) + 1
         val = rng.uniform(-1, 1, len(col_ind))
         x = rng.random(cols)
