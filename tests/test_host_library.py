@@ -329,3 +329,20 @@ def test_parallel_tokeniser_on_sample_and_fallbacks(tmp_path, monkeypatch):
     with pytest.raises(sm.SmvpError) as e:
         sm.mm_read_coo(str(p))
     assert e.value.code == sm.MM_PREMATURE_EOF
+
+
+def test_round3_entry_points_reject_bad_arguments_without_a_device():
+    """The plan controls added in round 3 validate their arguments before anything touches a GPU."""
+    import ctypes as C
+
+    L = sm.lib()
+    v, n, c = C.c_double(), C.c_int(), C.c_longlong()
+    assert L.smvp_csr_gather_spread(None, C.byref(v)) == sm.ERR_INVALID
+    assert L.smvp_csr_plan_launches(None, C.byref(n)) == sm.ERR_INVALID
+    assert L.smvp_tjds_set_value_cache(None, 4) == sm.ERR_INVALID
+    assert L.smvp_tjds_get_value_cache(None, C.byref(n), C.byref(c)) == sm.ERR_INVALID
+    assert L.smvp_vector_random(None, 5, 1) == sm.ERR_INVALID
+    assert L.smvp_vector_random(None, 0, 1) == sm.OK                       # nothing to write
+    assert "bad argument" in L.smvp_last_error().decode() or L.smvp_last_error().decode() == ""
+    x = sm.vector_random(7, 3)
+    assert np.array_equal(x, sm.vector_random(9, 3)[:7]) and not np.array_equal(x, sm.vector_random(7, 4))
