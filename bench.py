@@ -822,6 +822,11 @@ def main():
                "sample": "the full workload matrix, %d products of the serial loop (oracle restatement of "
                          "main-cli.c:410-416, gcc -O3 -DNDEBUG, y reset outside the window)" % iters,
                "agrees_with_gpu": bool(np.all(np.abs(y_cpu - res["got"]) <= TOL * res["scale"])),
+               # SURVEY 8(c) asks for these two beside the row-normwise bound: element-wise relative error (large only on
+               # rows whose sum cancels to ~1e-15 of its terms, whatever the order) and the infinity-norm error of y
+               "max_elementwise_rel_error": float((np.abs(y_cpu - res["got"]) / np.maximum(np.abs(y_cpu), 1e-300))[y_cpu != 0].max())
+               if np.any(y_cpu != 0) else 0.0,
+               "inf_norm_rel_error": float(np.abs(y_cpu - res["got"]).max() / max(float(np.abs(y_cpu).max()), 1e-300)),
                "gpu_rows_bit_identical_to_serial": round(float((y_cpu == res["got"]).mean()), 4)}
         # context only, NOT the reference (which is one thread): the same serial loop on every core of this host, each
         # thread on its own run of rows (ctypes releases the GIL inside the C loop)
