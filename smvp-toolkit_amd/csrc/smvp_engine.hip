@@ -318,8 +318,8 @@ void try_column_offsets(smvp_csr *h)
     if (h->flavor != smvp::kFlavorCsr || h->kernel != SMVP_CSR_KERNEL_STREAM || h->vpt < 4 || h->nnz <= 0 || (env && atoi(env) == 0))
         return;
     std::vector<int> tiles;
-    if (!h->tile_chosen && h->nnz >= 48 * 1024 * 1024)
-        tiles.push_back(2048);
+    if (!h->tile_chosen && h->nnz >= 12 * 1024 * 1024)  // memplus x59 / x118 / x236 (7.4 / 14.9 / 29.8 M entries), 1024- against
+        tiles.push_back(2048);                           // 2048-entry tiles: 0.0220 / 0.0364 / 0.0851 against 0.0219 / 0.0345 / 0.0787 ms
     tiles.push_back(smvp::kStreamBlock * h->vpt);
     const size_t max_tiles = ((size_t)h->nnz + 1023) / 1024 + 1;
     if (hipMalloc((void **)&h->d_col_base, max_tiles * sizeof(int)) == hipSuccess &&
