@@ -456,9 +456,10 @@ bool choose_csr_kernel(smvp_csr *h, int kernel, int param)
         h->tile_chosen = param > 0;
         if (tile == 0) {  // 1024 measured 1-4 % ahead of 2048 on memplus x944 and pwt x459; 256-entry tiles when
             tile = (kernel == SMVP_CSR_KERNEL_STREAM && h->nnz < 512 * 1024) ? 256 : 1024;  // 1024 would leave CUs idle
-            if ((h->flavor == smvp::kFlavorTjdsS || h->flavor == smvp::kFlavorTjdsH) && tile == 1024 && h->nnz >= 48 * 1024 * 1024)
-                tile = 2048;  // more entries per val line inside a tile: 0.553 vs 0.588 ms on memplus x944 (119 M entries);
-                              // below that 1024 wins (14 M entries: 0.0630 vs 0.0663 ms; 3.5 M: 0.0201 vs 0.0219)
+            if ((h->flavor == smvp::kFlavorTjdsS || h->flavor == smvp::kFlavorTjdsH) && tile == 1024 && h->nnz >= 12 * 1024 * 1024)
+                tile = 2048;  // more entries per val line inside a tile.  With the value cache and the 16-bit second word (round 3),
+                              // memplus x59 / x118 / x236 / x472 (7.4 / 14.9 / 29.8 / 59.5 M entries), 1024 against 2048:
+                              // 0.0285 / 0.0530 / 0.1157 / 0.2327 against 0.0280 / 0.0493 / 0.1070 / 0.2151 ms
         }
         h->vpt = tile / smvp::kStreamBlock;
     }
