@@ -153,8 +153,13 @@ int smvp_device_info(int device, char *name, size_t name_cap, int *compute_units
 
 /* CSR kernel families (smvp_csr_set_kernel).  AUTO picks STREAM; STREAM_CARRY when some row is longer
  * than 16384 entries; COLSWEEP for a large matrix whose gathers scatter over an operand much larger than
- * the L2 (measured at create time on samples of col_ind).  Every family gives the same result from run
- * to run. */
+ * the L2 (measured at create time on samples of col_ind: spread >= 0.6, rows long enough for the sweep's
+ * window); BINNED for a large matrix of which a good share (>= 10 %) of the entries lies far from the
+ * diagonal and scatters (spread >= 0.2) -- SURVEY 8(d)'s memplus-shaped random model.  Every family gives
+ * the same result from run to run, bit for bit.
+ * COLSWEEP, BINNED, the 16-bit column offsets of STREAM and the TJDS value cache keep (parts of) the entries a
+ * second time, copied when the plan is built: a handle over adopted device arrays (SMVP_MEM_DEVICE) whose
+ * val / col_ind are then changed in place must be re-planned (smvp_csr_set_kernel) or re-created. */
 enum {
     SMVP_CSR_KERNEL_AUTO = 0,
     SMVP_CSR_KERNEL_VECTOR = 1,      /* one (sub-)wavefront per row, __shfl_down sums */
@@ -164,11 +169,23 @@ enum {
                                         smallest column and the product reads those (same sums, fewer bytes) */
     SMVP_CSR_KERNEL_STREAM_CARRY = 3, /* same tiles; a row that crosses tiles is combined from per-tile carries
                                          by a second small launch (for matrices with extremely long rows) */
-    SMVP_CSR_KERNEL_COLSWEEP = 4      /* for columns scattered over an operand far larger than L2: strips of rows whose
+    SMVP_CSR_KERNEL_COLSWEEP = 4,     /* for columns scattered over an operand far larger than L2: strips of rows whose
                                          entries (kept a second time, sorted by column) are streamed so that all
                                          resident wavefronts gather from one L2-sized window of x; every row is
-                                         summed in ascending column order like main-cli.c:410-416 (bit-identical to
-                                         it).  param: rows per workgroup of four strips (1024 ... 8192) */
+                                         summed in ascending order of the strip's stream, i.e. of the columns: for
+                                         rows stored with ascending columns (what smvp_csr_from_coo and the reference
+                                         build) bit-identical to main-cli.c:410-416; for a row whose col_ind is not
+                                         ascending the sum is reproducible and within the rounding bound, but its
+                                         order is not the serial loop's.  param: rows per workgroup of four strips
+                                         (1024 ... 8192) */
+    SMVP_CSR_KERNEL_BINNED = 5        /* for matrices with a band around the diagonal plus many entries far from it
+                                         (anywhere in an operand much larger than the L2): the entries are kept a second
+                                         time, split by |column - row| > band.  The near part runs on STREAM.  The far
+                                         part never gathers from memory: pass A -- one workgroup per block of 16384
+                                         columns, that block of x in LDS -- stores every far product into bins ordered
+                                         (row block, column block); pass B -- one workgroup per row block -- sums each
+                                         row's far products in ascending column order and adds them to the near sum.
+                                         No atomics.  param: the band (0 = 4096) */
 };
 enum {
     SMVP_MEM_HOST = 0,  /* arrays are host memory: copied to the device */
@@ -197,9 +214,19 @@ int smvp_csr_spmv(smvp_csr_t *h, const double *d_x, double *d_y, void *stream);
 /* Name of the dominant kernel symbol of the current plan and its algorithmic
  * byte count per launch: 12*nnz + 4*(rows+1) + 8*cols + 8*rows. */
 int smvp_csr_describe(const smvp_csr_t *h, char *kernel_name, size_t cap, double *alg_bytes);
-/* Kernel launches per product of the current plan: 1, except STREAM_CARRY (2: tiles + carry fix-up) and COLSWEEP
- * (its workgroups start in generations that are resident together; config 4 on one GPU: 5). */
+/* Kernel launches per product of the current plan: 1, except STREAM_CARRY (2: tiles + carry fix-up), COLSWEEP
+ * (its workgroups start in generations that are resident together; config 4 on one GPU: 5) and BINNED (3: near part,
+ * far products, far sums). */
 int smvp_csr_plan_launches(const smvp_csr_t *h, int *launches);
+/* What the current launch plan costs (the reference has no counterpart: its set-up is the three qsorts and the
+ * O(nnz * N) renumbering of main-cli.c:340,766-926, untimed): bytes of HBM the format's own arrays take, bytes the plan
+ * keeps beside them (second copies included), and the host wall time the last plan build took, device work included. */
+typedef struct smvp_plan_info {
+    double matrix_bytes; /* CSR: 12 nnz + 4 (rows + 1); TJDS: 12 nnz + 4 (D + 1) + 4 cols */
+    double plan_bytes;
+    double build_ms;
+} smvp_plan_info_t;
+int smvp_csr_plan_info(const smvp_csr_t *h, smvp_plan_info_t *out);
 void smvp_csr_destroy(smvp_csr_t *h);
 
 /* Device-side half of smvp_tjds_compute (main-cli.c:756-763,944-967): val,
@@ -248,6 +275,7 @@ int smvp_tjds_get_value_cache(const smvp_tjds_t *h, int *min_tiles, long long *c
  * by row: main-cli.c:865,951-966,1018).  A host-side edit of the launch plan of the atomic kernel. */
 int smvp_tjds_set_ref_quirks(smvp_tjds_t *h, int enable, int ref_num_tjdiag, int last_diag_single);
 int smvp_tjds_describe(const smvp_tjds_t *h, char *kernel_name, size_t cap, double *alg_bytes);
+int smvp_tjds_plan_info(const smvp_tjds_t *h, smvp_plan_info_t *out); /* plan: x_perm, the work items, the selected modes' plans */
 void smvp_tjds_destroy(smvp_tjds_t *h);
 
 /* ------------------------------------------- several GPUs, one host process */

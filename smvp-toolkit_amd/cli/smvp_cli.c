@@ -19,7 +19,7 @@
  *     reference (host-only work, no GPU; --all-algs stays CSR + TJDS).
  *   - libpopt is not used (absent from the image): getopt_long("+...") gives the
  *     same POSIX ordering rule.
- * Additive flags: --device N, --gpus N, --iterate, --normalize, --ref-quirks, --device-convert, --csr-kernel auto|vector|stream|stream-carry|colsweep,
+ * Additive flags: --device N, --gpus N, --iterate, --normalize, --ref-quirks, --device-convert, --csr-kernel auto|vector|stream|stream-carry|colsweep|binned,
  * --tjds-mode auto|row-gather|two-phase|atomic, --timing auto|events|device, --expand-symmetric, --cache,
  * --x ones|random, --dump-arrays.  The reference's shipped binary prints whole arrays (SMVP_CSR_DEBUG 1,
  * main-cli.c:10,374-394,458-466,1166-1191); here those dumps -- and the TJDS ones its source holds behind
@@ -52,7 +52,7 @@ static void usage(FILE *to, const char *prog)
     fprintf(to,
             "Usage: %s [-acgt?] [-a|--all-algs] [-c|--csr] [-g|--cisr-gen] [-t|--tjds]\n"
             "        [-n|--number=1000] [-s|--slots=16] [-d|--dir=./] [--device=0] [--gpus=1]\n"
-            "        [--ref-quirks] [--iterate] [--normalize] [--device-convert] [--csr-kernel=auto|vector|stream|stream-carry|colsweep]\n"
+            "        [--ref-quirks] [--iterate] [--normalize] [--device-convert] [--csr-kernel=auto|vector|stream|stream-carry|colsweep|binned]\n"
             "        [--tjds-mode=auto|row-gather|two-phase|atomic] [--timing=auto|events|device]\n"
             "        [--expand-symmetric] [--cache] [--x=ones|random] [--dump-arrays]\n"
             "        [-?|--help] [--usage]\n"
@@ -77,7 +77,7 @@ static void help(const char *prog)
     puts("      --normalize          --iterate, and divide every iterate by its largest magnitude.");
     puts("      --ref-quirks         Reproduce the reference v0.6.4 TJDS output, defects included.");
     puts("      --device-convert     Build CSR / TJDS from the loaded entries on the GPU instead of the host.");
-    puts("      --csr-kernel=auto    CSR kernel family: auto, vector, stream, stream-carry, colsweep.");
+    puts("      --csr-kernel=auto    CSR kernel family: auto, vector, stream, stream-carry, colsweep, binned.");
     puts("      --tjds-mode=auto     TJDS product: auto (= row-gather, one kernel), two-phase, atomic.");
     puts("      --timing=auto        Per-product window: events (hipEvent pair), device (the kernel times itself), auto.");
     puts("      --expand-symmetric   Mirror the stored triangle of a symmetric file (the reference multiplies it as stored).");
@@ -366,8 +366,10 @@ int main(int argc, char *argv[])
                 csr_kernel = SMVP_CSR_KERNEL_STREAM_CARRY;
             else if (strcmp(optarg, "colsweep") == 0)
                 csr_kernel = SMVP_CSR_KERNEL_COLSWEEP;
+            else if (strcmp(optarg, "binned") == 0)
+                csr_kernel = SMVP_CSR_KERNEL_BINNED;
             else
-                die("Unknown CSR kernel family (use auto, vector, stream, stream-carry or colsweep).");
+                die("Unknown CSR kernel family (use auto, vector, stream, stream-carry, colsweep or binned).");
             break;
         case OPT_TIMING:
             if (strcmp(optarg, "auto") == 0)

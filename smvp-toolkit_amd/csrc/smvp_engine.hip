@@ -126,7 +126,7 @@ struct smvp_csr {
     // A line split over two or three tiles is the edge between neighbouring tiles (they run together on one XCD: an L2
     // hit); from four on its entries belong to unrelated rows.  Measured on memplus x944 (profiles/r03_tjds_forms_measured.txt):
     // none 0.555 ms / 3.66 GB moved, >= 8 tiles 0.461 / 2.92 (20 % of the values cached), >= 4 tiles 0.444 / 2.73 (35 %).
-    int cache_min_tiles = 4, cached_total = 0;
+    int cache_min_tiles = 4, cached_total = 0, ovf_total = 0;
     int *d_cache_ptr = nullptr;
     double *d_val_cache = nullptr;
     // TjdsH: the 16-bit second word of every entry, the tiles' runs (start_pos of each run's diagonal), each group of 32's run
@@ -155,9 +155,24 @@ struct smvp_csr {
     int *d_sweep_col = nullptr;
     double *d_sweep_val = nullptr;
     unsigned short *d_sweep_row = nullptr;
+    // BINNED: the entries a second time, split by |column - row| > band: the near part as CSR arrays of its own, run by
+    // the tile kernel through the nested handle `near`; the far part as the two streams and the bins of smvp_binned.hip
+    smvp::BinnedPlan bin;
+    smvp_csr *near = nullptr;
+    double far_share = -2.0;   // share of entries with |column - row| > kBinNearBand; -2: not measured yet
+    bool plain_only = false;   // a nested handle: AUTO stays on the tile kernels
+    int sweep_g = 0;           // COLSWEEP: chunks in flight per wavefront (fixed when the plan is built)
+    double plan_build_ms = 0.0;  // host wall time of the last plan build
 };
 
 namespace {
+
+void free_binned(smvp_csr *h)
+{
+    smvp_csr_destroy(h->near);
+    h->near = nullptr;
+    smvp::free_binned_plan(&h->bin);
+}
 
 void free_sweep_plan(smvp_csr *h)
 {
@@ -194,7 +209,7 @@ void choose_sweep_shape(int rows, int cols, int nnz, int want_rb, int *rb, int *
         if (hgt.rows < floor_rb)
             continue;
         const int nrb = (rows + hgt.rows - 1) / hgt.rows;
-        const double fill = (double)nrb / (generations(nrb) * 256.0);
+        const double fill = (double)nrb / (std::max(1, generations(nrb)) * 256.0);
         if (fill * hgt.rate > best) {
             best = fill * hgt.rate;
             r = hgt.rows;
@@ -203,8 +218,9 @@ void choose_sweep_shape(int rows, int cols, int nnz, int want_rb, int *rb, int *
     if (want_rb > 0)
         r = want_rb;
     const int nrb = (rows + r - 1) / r;
+    const int gen = std::max(1, generations(nrb));  // no rows: one (empty) generation
     *rb = r;
-    *per_launch = (nrb + generations(nrb) - 1) / generations(nrb);
+    *per_launch = std::max(1, (nrb + gen - 1) / gen);
 }
 
 int build_sweep_plan(smvp_csr *h, int want_rb)
@@ -212,6 +228,7 @@ int build_sweep_plan(smvp_csr *h, int want_rb)
     free_sweep_plan(h);
     choose_sweep_shape(h->rows, h->cols, h->nnz, want_rb, &h->sweep_rb, &h->sweep_per_launch);
     const int strip_rows = h->sweep_rb / smvp::kSweepWaves;
+    h->sweep_g = smvp::sweep_chunks_in_flight(strip_rows);
     const int nstrips = (h->rows + strip_rows - 1) / strip_rows;
     const size_t n = (size_t)std::max(h->nnz, 4);
     if (hipMalloc((void **)&h->d_sweep_ptr, ((size_t)nstrips + 2) * sizeof(long long)) != hipSuccess ||
@@ -263,7 +280,7 @@ double csr_gather_spread(const smvp_csr *h)
 constexpr double kSweepMinSpread = 0.6;
 bool sweep_suits(smvp_csr *h)
 {
-    if (h->flavor != smvp::kFlavorCsr || h->nnz < 4 * 1024 * 1024 || h->rows < 4096)
+    if (h->plain_only || h->flavor != smvp::kFlavorCsr || h->nnz < 4 * 1024 * 1024 || h->rows < 4096)
         return false;
     const double mean = (double)h->nnz / h->rows;
     if (mean < 4.0 || (double)h->cols * 8.0 < 8.0 * 1024 * 1024 || 8192.0 * mean * 160.0 < (double)h->cols ||
@@ -272,6 +289,36 @@ bool sweep_suits(smvp_csr *h)
     if (h->spread < -1.5)
         h->spread = csr_gather_spread(h);
     return h->spread >= kSweepMinSpread;
+}
+
+// AUTO picks the binned plan (near part on the tile kernel, far part in two LDS-binned passes: smvp_binned.hip) where the
+// tile kernel is held back by gathers that miss the L2 and the column sweep does not fit:
+//  * a large matrix (>= 4 M entries) over an operand of at least 16 MB;
+//  * a good share of the gathers pull their own line of x: spread >= kBinnedMinSpread (the SURVEY 8(d) random model: 0.40,
+//    tile kernel 1.03 ms; kron(I, memplus), pwt x459, a narrow band: < 0.1, which stay on the tile kernel);
+//  * and those gathers are what the split removes: at least kBinnedMinFarShare of the entries lie further than
+//    kBinNearBand from the diagonal (the model: 0.39).  A matrix whose scattered gathers are close to the diagonal
+//    gains nothing from the split.
+// The column sweep is asked first (spread >= 0.6 and rows long enough for its window: BASELINE config 4).
+constexpr double kBinnedMinSpread = 0.2, kBinnedMinFarShare = 0.1;
+bool binned_suits(smvp_csr *h)
+{
+    if (h->plain_only || h->flavor != smvp::kFlavorCsr || h->nnz < 4 * 1024 * 1024 || h->rows < 4096 ||
+        (double)h->cols * 8.0 < 16.0 * 1024 * 1024)
+        return false;
+    if (h->spread < -1.5)
+        h->spread = csr_gather_spread(h);
+    if (h->spread < kBinnedMinSpread)
+        return false;
+    if (h->far_share < -1.5) {
+        double share = -1.0;
+        if (smvp::csr_far_share(h->d_row_ptr, h->d_col_ind, h->rows, h->nnz, smvp::kBinNearBand, &share, nullptr) != SMVP_OK) {
+            (void)hipGetLastError();
+            share = -1.0;
+        }
+        h->far_share = share;
+    }
+    return h->far_share >= kBinnedMinFarShare;
 }
 
 void free_stream_plan(smvp_csr *h)
@@ -384,6 +431,7 @@ int build_stream_plan(smvp_csr *h)
             ovf_ptr[(size_t)b + 1] = ovf_ptr[(size_t)b] + (owns ? (int)(tile_next[(size_t)b] - e) : 0);
         }
         const int total = ovf_ptr[(size_t)ntiles];
+        h->ovf_total = total;
         if (int rc = upload(&h->d_ovf_ptr, ovf_ptr))
             return rc;
         const size_t n = (size_t)std::max(h->nnz, 4), m = (size_t)std::max(total, 4);
@@ -439,6 +487,7 @@ bool choose_csr_kernel(smvp_csr *h, int kernel, int param)
     if (kernel == SMVP_CSR_KERNEL_AUTO)
         kernel = h->max_row_len > kOwnerMaxRow ? SMVP_CSR_KERNEL_STREAM_CARRY
                  : sweep_suits(h)              ? SMVP_CSR_KERNEL_COLSWEEP
+                 : binned_suits(h)             ? SMVP_CSR_KERNEL_BINNED
                                                : SMVP_CSR_KERNEL_STREAM;
     if (kernel == SMVP_CSR_KERNEL_STREAM && param != 0 && param != 256 && param != 1024 && param != 2048)
         return false;
@@ -446,8 +495,10 @@ bool choose_csr_kernel(smvp_csr *h, int kernel, int param)
         return false;
     if (kernel == SMVP_CSR_KERNEL_COLSWEEP && param != 0 && param != 1024 && param != 2048 && param != 4096 && param != 8192)
         return false;
+    if (kernel == SMVP_CSR_KERNEL_BINNED && param < 0)
+        return false;
     h->kernel = kernel;
-    if (kernel == SMVP_CSR_KERNEL_COLSWEEP)
+    if (kernel == SMVP_CSR_KERNEL_COLSWEEP || kernel == SMVP_CSR_KERNEL_BINNED)
         return true;
     if (kernel == SMVP_CSR_KERNEL_VECTOR) {
         h->lanes_per_row = param > 0 ? param : pow2_at_least(mean);
@@ -475,9 +526,13 @@ struct TjdsSource {
     int num_diag = 0;
 };
 
+static int build_binned(smvp_csr *h, int band);
+static double wall_ms();
+
 static int csr_create_impl(smvp_csr_t **out, int device, int rows, int cols, int nnz,
                            const int *row_ptr, const int *col_ind, const double *val,
-                           int mem_kind, const int *host_row_ptr, int flavor, const TjdsSource *src = nullptr)
+                           int mem_kind, const int *host_row_ptr, int flavor, const TjdsSource *src = nullptr,
+                           bool plain_only = false)
 {
     const bool unit_val = flavor == smvp::kFlavorUnit;
     const bool plain = flavor == smvp::kFlavorCsr;
@@ -495,6 +550,7 @@ static int csr_create_impl(smvp_csr_t **out, int device, int rows, int cols, int
     smvp_csr *h = new smvp_csr;
     h->device = device;
     h->flavor = flavor;
+    h->plain_only = plain_only;
     if (src) {
         h->d_pos = src->pos, h->d_start_pos = src->start_pos;
         h->num_diag = src->num_diag;
@@ -539,17 +595,21 @@ static int csr_create_impl(smvp_csr_t **out, int device, int rows, int cols, int
     if (rc == SMVP_OK && !unit_val)
         rc = to_device(&h->d_val, val, (size_t)nnz, mem_kind, &h->own_val);
     if (rc == SMVP_OK) {
+        const double t0 = wall_ms();
         // every flavour but plain CSR exists for the owner-completes kernel only
         choose_csr_kernel(h, plain ? SMVP_CSR_KERNEL_AUTO : SMVP_CSR_KERNEL_STREAM, 0);
-        if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP && build_sweep_plan(h, 0) != SMVP_OK) {
+        if ((h->kernel == SMVP_CSR_KERNEL_COLSWEEP && build_sweep_plan(h, 0) != SMVP_OK) ||
+            (h->kernel == SMVP_CSR_KERNEL_BINNED && build_binned(h, 0) != SMVP_OK)) {
             // AUTO's second copy of the entries did not fit: the tile kernel needs none
             (void)hipGetLastError();
             free_sweep_plan(h);
+            free_binned(h);
             h->spread = -1.0;
             choose_csr_kernel(h, SMVP_CSR_KERNEL_STREAM, 0);
         }
-        if (h->kernel != SMVP_CSR_KERNEL_VECTOR && h->kernel != SMVP_CSR_KERNEL_COLSWEEP)
+        if (h->kernel != SMVP_CSR_KERNEL_VECTOR && h->kernel != SMVP_CSR_KERNEL_COLSWEEP && h->kernel != SMVP_CSR_KERNEL_BINNED)
             rc = build_stream_plan(h);
+        h->plan_build_ms = wall_ms() - t0;
     }
     if (rc != SMVP_OK) {
         smvp_csr_destroy(h);
@@ -566,13 +626,30 @@ extern "C" int smvp_csr_create(smvp_csr_t **out, int device, int rows, int cols,
     return csr_create_impl(out, device, rows, cols, nnz, row_ptr, col_ind, val, mem_kind, host_row_ptr, smvp::kFlavorCsr);
 }
 
+static double wall_ms()
+{
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+
+// The binned plan: near / far split on the device, the near part behind a nested handle that stays on the tile kernels.
+static int build_binned(smvp_csr *h, int band)
+{
+    free_binned(h);
+    if (int rc = smvp::build_binned_plan(h->d_row_ptr, h->d_col_ind, h->d_val, h->rows, h->cols, h->nnz, band, &h->bin, nullptr))
+        return rc;
+    return csr_create_impl(&h->near, h->device, h->rows, h->cols, h->bin.nnz_near, h->bin.near_ptr, h->bin.near_col, h->bin.near_val,
+                           SMVP_MEM_DEVICE, nullptr, smvp::kFlavorCsr, nullptr, true);
+}
+
 extern "C" int smvp_csr_set_kernel(smvp_csr_t *h, int kernel, int param)
 {
     if (!h)
         return smvp::fail(SMVP_ERR_INVALID, "null handle");
     if (h->flavor != smvp::kFlavorCsr && kernel != SMVP_CSR_KERNEL_STREAM)
         return smvp::fail(SMVP_ERR_UNSUPPORTED, "this matrix flavour runs on the stream kernel only");
-    if (kernel < SMVP_CSR_KERNEL_AUTO || kernel > SMVP_CSR_KERNEL_COLSWEEP)
+    if (kernel < SMVP_CSR_KERNEL_AUTO || kernel > SMVP_CSR_KERNEL_BINNED)
         return smvp::fail(SMVP_ERR_INVALID, "unknown CSR kernel %d", kernel);
     if (kernel == SMVP_CSR_KERNEL_VECTOR && param != 0 &&
         (param < 2 || param > 64 || (param & (param - 1)) != 0))
@@ -580,16 +657,35 @@ extern "C" int smvp_csr_set_kernel(smvp_csr_t *h, int kernel, int param)
     DeviceScope on(h->device);
     if (!choose_csr_kernel(h, kernel, param))
         return smvp::fail(SMVP_ERR_INVALID, "entries per tile must be 256 (stream only), 1024 or 2048 for the kernel "
-                                            "this matrix resolves to (column sweep: 1024 ... 8192 rows per block)");
+                                            "this matrix resolves to (column sweep: 1024 ... 8192 rows per block; binned: the near band, >= 0)");
+    const double t0 = wall_ms();
     free_sweep_plan(h);
-    if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP) {
+    free_binned(h);
+    int rc = SMVP_OK;
+    if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP || h->kernel == SMVP_CSR_KERNEL_BINNED) {
         free_stream_plan(h);
-        return build_sweep_plan(h, param);
+        rc = h->kernel == SMVP_CSR_KERNEL_COLSWEEP ? build_sweep_plan(h, param) : build_binned(h, param);
+        if (rc != SMVP_OK) {
+            // the second copy of the entries did not fit (or could not be built): back to the tile kernel, which needs
+            // none, so that the handle stays usable -- the error is still reported
+            const std::string why = smvp_last_error();
+            (void)hipGetLastError();
+            free_sweep_plan(h);
+            free_binned(h);
+            h->spread = -1.0;
+            choose_csr_kernel(h, SMVP_CSR_KERNEL_STREAM, 0);
+            if (build_stream_plan(h) != SMVP_OK)
+                free_stream_plan(h);  // smvp_csr_spmv refuses a handle without a plan
+            h->plan_build_ms = wall_ms() - t0;
+            return smvp::fail(rc, "%s", why.c_str());
+        }
+    } else if (h->kernel != SMVP_CSR_KERNEL_VECTOR) {
+        rc = build_stream_plan(h);
+    } else {
+        free_stream_plan(h);
     }
-    if (h->kernel != SMVP_CSR_KERNEL_VECTOR)
-        return build_stream_plan(h);
-    free_stream_plan(h);
-    return SMVP_OK;
+    h->plan_build_ms = wall_ms() - t0;
+    return rc;
 }
 
 extern "C" int smvp_csr_get_kernel(const smvp_csr_t *h, int *kernel, int *param)
@@ -600,7 +696,9 @@ extern "C" int smvp_csr_get_kernel(const smvp_csr_t *h, int *kernel, int *param)
         *kernel = h->kernel;
     if (param)
         *param = h->kernel == SMVP_CSR_KERNEL_VECTOR ? h->lanes_per_row
-                 : h->kernel == SMVP_CSR_KERNEL_COLSWEEP ? h->sweep_rb : h->vpt * smvp::kStreamBlock;
+                 : h->kernel == SMVP_CSR_KERNEL_COLSWEEP ? h->sweep_rb
+                 : h->kernel == SMVP_CSR_KERNEL_BINNED   ? h->bin.band
+                                                         : h->vpt * smvp::kStreamBlock;
     return SMVP_OK;
 }
 
@@ -620,15 +718,27 @@ static int csr_spmv_impl(smvp_csr_t *h, const double *d_x, double *d_y, void *st
 {
     if (!h || (h->rows > 0 && !d_y) || (h->nnz > 0 && !d_x))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_spmv: bad argument");
-    if ((h->kernel == SMVP_CSR_KERNEL_COLSWEEP && !h->d_sweep_ptr) ||
-        (h->kernel != SMVP_CSR_KERNEL_VECTOR && h->kernel != SMVP_CSR_KERNEL_COLSWEEP && !h->d_tile_row))
+    if ((h->kernel == SMVP_CSR_KERNEL_COLSWEEP && !h->d_sweep_ptr) || (h->kernel == SMVP_CSR_KERNEL_BINNED && !h->near) ||
+        (h->kernel != SMVP_CSR_KERNEL_VECTOR && h->kernel != SMVP_CSR_KERNEL_COLSWEEP && h->kernel != SMVP_CSR_KERNEL_BINNED &&
+         !h->d_tile_row))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_spmv: the handle has no launch plan (a re-plan failed earlier)");
     DeviceScope on(h->device);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
-    if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP)
+    if (h->kernel == SMVP_CSR_KERNEL_BINNED) {
+        // the near part writes every row of y; pass A puts the far products into the bins; pass B adds each row's far sum.
+        // (Pass A needs x only and was tried on a stream of its own beside the near product: its one workgroup per CU --
+        // 132 KB of LDS -- only gets onto a CU once the tile kernel's six have drained, so the two ran one after the other
+        // anyway: 0.777 against 0.757 ms, profiles/r04_binned_measured.txt.)
+        if (int rc = csr_spmv_impl(h->near, d_x, d_y, stream, nullptr))
+            return rc;
+        e = smvp::launch_binned_products(h->bin, d_x, st);
+        if (e != hipSuccess)
+            return smvp::fail(SMVP_ERR_HIP, "CSR launch failed: %s", hipGetErrorString(e));
+        e = smvp::launch_binned_sums(h->bin, d_y, st);
+    } else if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP)
         e = smvp::launch_csr_colsweep(h->d_sweep_ptr, h->d_sweep_col, h->d_sweep_val, h->d_sweep_row, d_x, d_y, h->rows,
-                                      h->sweep_rb / smvp::kSweepWaves, h->sweep_per_launch, st);
+                                      h->sweep_rb / smvp::kSweepWaves, h->sweep_per_launch, h->sweep_g, st);
     else if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
         e = smvp::launch_csr_vector(h->lanes_per_row, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y, h->rows, st);
     else if (h->kernel == SMVP_CSR_KERNEL_STREAM) {
@@ -667,8 +777,12 @@ extern "C" int smvp_csr_describe(const smvp_csr_t *h, char *kernel_name, size_t 
     if (!h)
         return smvp::fail(SMVP_ERR_INVALID, "null handle");
     if (kernel_name && cap) {
-        if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP)
-            snprintf(kernel_name, cap, "csr_colsweep<%d>", smvp::sweep_chunks_in_flight(h->sweep_rb / smvp::kSweepWaves));
+        if (h->kernel == SMVP_CSR_KERNEL_BINNED)
+            snprintf(kernel_name, cap, "csr_binned: csr_stream_owner<%d, %d, false> + csr_binned_far_products<2> + csr_binned_far_sums<%d, %d, 2>",
+                     h->near ? h->near->vpt : 0, h->near ? (h->near->d_col16 ? smvp::kFlavorCsr16 : h->near->flavor) : 0,
+                     h->bin.slots, h->bin.threads_b);
+        else if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP)
+            snprintf(kernel_name, cap, "csr_colsweep<%d>", h->sweep_g);
         else if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
             snprintf(kernel_name, cap, "csr_vector_rows<%d>", h->lanes_per_row);
         else if (h->kernel == SMVP_CSR_KERNEL_STREAM)
@@ -692,7 +806,45 @@ extern "C" int smvp_csr_plan_launches(const smvp_csr_t *h, int *launches)
         *launches = std::max(1, (nwg + h->sweep_per_launch - 1) / h->sweep_per_launch);
     } else if (h->kernel == SMVP_CSR_KERNEL_STREAM_CARRY && h->ntiles > 1) {
         *launches = 2;
+    } else if (h->kernel == SMVP_CSR_KERNEL_BINNED && h->near) {
+        int near = 1;
+        (void)smvp_csr_plan_launches(h->near, &near);
+        *launches = near + (h->bin.nf > 0 ? 2 : 0);
     }
+    return SMVP_OK;
+}
+
+// bytes of device memory the current launch plan keeps beside row_ptr / col_ind / val
+static double csr_plan_bytes(const smvp_csr_t *h)
+{
+    const double n = h->nnz, t = h->ntiles;
+    if (h->kernel == SMVP_CSR_KERNEL_BINNED)
+        return (double)h->bin.plan_bytes + (h->near ? csr_plan_bytes(h->near) : 0.0);
+    if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP) {
+        const int strip_rows = std::max(1, h->sweep_rb / smvp::kSweepWaves);
+        return 14.0 * n + 8.0 * ((h->rows + strip_rows - 1) / strip_rows + 2);
+    }
+    if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
+        return 0.0;
+    double b = 4.0 * (t + 1) + 4.0 * t;  // tile_row + tile_next (or carry_row)
+    if (h->kernel == SMVP_CSR_KERNEL_STREAM_CARRY)
+        b += 8.0 * t;
+    if (h->d_col16)
+        b += 2.0 * n + 4.0 * (n / 1024 + 1);
+    if (h->flavor == smvp::kFlavorTjdsS || h->flavor == smvp::kFlavorTjdsH) {
+        b += 4.0 * n + 4.0 * (t + 1) + 8.0 * h->ovf_total + 4.0 * (t + 2) + 8.0 * h->cached_total;
+        b += h->flavor == smvp::kFlavorTjdsH ? 2.0 * n + 4.0 * (t + 2) + 4.0 * h->runs_total + 2.0 * (n / 32 + 1) : 4.0 * n;
+    }
+    return b;
+}
+
+extern "C" int smvp_csr_plan_info(const smvp_csr_t *h, smvp_plan_info_t *out)
+{
+    if (!h || !out)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_plan_info: bad argument");
+    out->matrix_bytes = 12.0 * h->nnz + 4.0 * (h->rows + 1.0);
+    out->plan_bytes = csr_plan_bytes(h);
+    out->build_ms = h->plan_build_ms;
     return SMVP_OK;
 }
 
@@ -701,8 +853,11 @@ extern "C" void smvp_csr_destroy(smvp_csr_t *h)
     if (!h)
         return;
     DeviceScope on(h->device);
+    smvp::debug_owner_phases();  // (print in diagnostic builds only)
+    smvp::debug_binned_phases();
     free_stream_plan(h);
     free_sweep_plan(h);
+    free_binned(h);
     if (h->own_row_ptr && h->d_row_ptr)
         (void)hipFree(h->d_row_ptr);
     if (h->own_col_ind && h->d_col_ind)
@@ -751,6 +906,7 @@ struct smvp_tjds {
     int4 *d_work = nullptr;
     int nwork = 0;
     long long planned_nnz = 0;
+    double plan_build_ms = 0.0;  // host wall time of the plan builds so far (work items + the modes' plans)
 };
 
 namespace {
@@ -939,10 +1095,12 @@ extern "C" int smvp_tjds_create(smvp_tjds_t **out, int device, int rows, int col
             hipMemset(h->d_x_perm, 0, n * sizeof(double)) != hipSuccess)
             rc = smvp::fail(SMVP_ERR_ALLOC, "smvp_tjds_create: cannot allocate the permuted operand");
     }
+    const double t0 = wall_ms();
     if (rc == SMVP_OK)
         rc = build_tjds_plan(h, false, 0, 0);
     if (rc == SMVP_OK)
         rc = ensure_mode_plan(h);
+    h->plan_build_ms = wall_ms() - t0;
     if (rc != SMVP_OK) {
         smvp_tjds_destroy(h);
         return rc;
@@ -958,10 +1116,12 @@ extern "C" int smvp_tjds_set_mode(smvp_tjds_t *h, int mode)
     DeviceScope on(h->device);
     const int before = h->mode;
     h->mode = mode == SMVP_TJDS_MODE_AUTO ? SMVP_TJDS_MODE_ROW_GATHER : mode;
+    const double t0 = wall_ms();
     if (int rc = ensure_mode_plan(h)) {
         h->mode = before;
         return rc;
     }
+    h->plan_build_ms += wall_ms() - t0;
     return SMVP_OK;
 }
 
@@ -1073,6 +1233,23 @@ extern "C" int smvp_tjds_get_value_cache(const smvp_tjds_t *h, int *min_tiles, l
         *min_tiles = on ? h->rg->cache_min_tiles : 0;
     if (cached_entries)
         *cached_entries = on ? h->rg->cached_total : 0;
+    return SMVP_OK;
+}
+
+extern "C" int smvp_tjds_plan_info(const smvp_tjds_t *h, smvp_plan_info_t *out)
+{
+    if (!h || !out)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_tjds_plan_info: bad argument");
+    const double n = h->nnz;
+    out->matrix_bytes = 12.0 * n + 4.0 * (h->num_diag + 1.0) + 4.0 * h->cols;
+    double b = 8.0 * std::max(h->rows, h->cols);             // x_perm
+    b += 4.0 * (h->num_diag + 3.0) + 16.0 * h->nwork;        // the column-major work items (atomic / two-phase / ref-quirks)
+    if (h->rg)
+        b += 4.0 * (h->rows + 4.0) + 4.0 * n + (h->d_rg_k ? 4.0 * n : 0.0) + csr_plan_bytes(h->rg);
+    if (h->inv)
+        b += 8.0 * n + 4.0 * (h->rows + 4.0) + 4.0 * n + csr_plan_bytes(h->inv);
+    out->plan_bytes = b;
+    out->build_ms = h->plan_build_ms;
     return SMVP_OK;
 }
 

@@ -52,6 +52,10 @@ struct OwnerLaunch {
     int rows = 0, nnz = 0, ntiles = 0;
 };
 hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hipStream_t stream);
+// diagnostic builds (make HIPFLAGS+=-DSMVP_PHASE_STAMPS): print and clear the mean time a workgroup of the owner kernel / of
+// the binned plan's pass B spent in each of its phases; nothing in a normal build
+void debug_owner_phases();
+void debug_binned_phases();
 int owner_stamp_slots(int ntiles, int flavor);  // {first, last} tick pairs one stamped launch writes
 hipError_t launch_stamp_reduce(const unsigned long long *stamps, int slots_per_product, int products,
                                unsigned long long *first_last, hipStream_t stream);
@@ -66,10 +70,60 @@ hipError_t launch_normalize_max(double *v, long long n, unsigned long long *scra
 hipError_t launch_fill(double *p, double v, long long n, hipStream_t stream);
 
 hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, const double *e_val, const unsigned short *e_row,
-                               const double *x, double *y, int rows, int strip_rows, int per_launch, hipStream_t stream);
-int sweep_chunks_in_flight(int strip_rows);  // the G of csr_colsweep<G> a strip height runs with
+                               const double *x, double *y, int rows, int strip_rows, int per_launch, int g, hipStream_t stream);
+int sweep_chunks_in_flight(int strip_rows);  // the G of csr_colsweep<G> a strip height runs with (reads SMVP_SWEEP_G: plan time only)
 // entries of 64 K-entry samples of a CSR matrix that gather from distinct 128-byte lines of x (see csr_line_spread)
 constexpr int kSpreadSpan = 64 * 1024;
 hipError_t launch_csr_line_spread(const int *col_ind, long long nnz, int samples, int *distinct, hipStream_t stream);
+
+// ---- K5: near / far split with a binned two-pass far product (smvp_binned.hip) ----
+constexpr int kBinColBits = 14;    // pass A: columns per block, 16384 = 128 KB of x in LDS
+constexpr int kBinSlots = 8192;    // pass B: far entries a row block holds at most (64 KB of products in LDS, two workgroups per CU)
+constexpr int kBinRowCap = 1024;   // a row with more far entries than this keeps all of them in the near part
+constexpr int kBinBucket = kBinSlots - kBinRowCap;  // a row block = the rows whose first far entry falls into one bucket of this many
+constexpr int kBinThreads = 1024;  // threads per workgroup, both passes
+constexpr int kBinShiftCap = 1024; // cell shifts of a group staged in LDS (the rest are read from memory); pass A's 132 KB leave
+                                   // room for one workgroup of the near product's tile kernel (25.8 KB) on the same CU
+constexpr int kBinNearBand = 4096; // default: an entry is far when |column - row| exceeds this
+
+// One grouped stream of the far entries (pass A: groups = column blocks, cells = super blocks of rows; pass B: groups =
+// row blocks, cells = column blocks): every group's entries one after the other, padded to a multiple of 64; a 16-bit word
+// per entry whose top bit marks the first entry of a cell; per cell the distance from the entry's place in this stream to
+// its product's place in the bins; per 64 entries the number (inside the group, minus one) of the cell the chunk starts in.
+// Groups are padded to whole 256-entry units, each stored interleaved for wide per-lane loads (smvp_binned.hip).
+struct BinnedStream {
+    int groups = 0, padded = 0, cells = 0;
+    unsigned short *word = nullptr;  // padded: 0xffff = padding
+    int *chunk = nullptr;            // padded / 64
+    int *ptr = nullptr;              // groups + 1 stream offsets (multiples of 256)
+    int *shift_ptr = nullptr;        // groups + 1 offsets into shift
+    int *shift = nullptr;            // cells
+};
+
+struct BinnedPlan {
+    int band = kBinNearBand;
+    int rows = 0, cols = 0, nnz = 0, nnz_near = 0, nf = 0;  // nf: far entries
+    int ncb = 0, nrb = 0, q = 1, nfr = 0, splits = 1;       // column blocks, row blocks, row blocks per super block, far rows
+    int slots = kBinSlots, threads_b = kBinThreads;          // pass B: far entries per row block at most (a row's cap is an eighth of it), threads per workgroup
+    // near part: its own CSR arrays (rows + 1, nnz_near, nnz_near), run by the tile kernel
+    int *near_ptr = nullptr, *near_col = nullptr;
+    double *near_val = nullptr;
+    // far part
+    double *a_val = nullptr;   // pass A stream: values (a.padded)
+    BinnedStream a, b;
+    double *bins = nullptr;    // nf products, ordered (super block, column block, row, column)
+    int *fr_row = nullptr, *fr_ptr = nullptr, *blk_fr = nullptr;  // far rows: row, first far entry (nfr + 1); first far row of each row block (nrb + 1)
+    size_t plan_bytes = 0;
+};
+void free_binned_plan(BinnedPlan *p);
+// near / far split of a device-resident CSR matrix and the far part's two streams, built on the device
+int build_binned_plan(const int *d_row_ptr, const int *d_col_ind, const double *d_val, int rows, int cols, int nnz, int band,
+                      BinnedPlan *out, hipStream_t stream);
+// far products into the bins (pass A: needs x only); y[row] += the row's far sum for every row with far entries (pass B:
+// after pass A, and after the near product has written y)
+hipError_t launch_binned_products(const BinnedPlan &p, const double *x, hipStream_t stream);
+hipError_t launch_binned_sums(const BinnedPlan &p, double *y, hipStream_t stream);
+// share (0 ... 1) of a CSR matrix's entries with |column - row| > band: what AUTO's choice of the binned plan rests on
+int csr_far_share(const int *d_row_ptr, const int *d_col_ind, int rows, int nnz, int band, double *share, hipStream_t stream);
 
 }  // namespace smvp

@@ -13,6 +13,7 @@
 // by one lane is bit-identical to the serial CPU result.
 #include "smvp_kernels.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace smvp {
@@ -278,6 +279,26 @@ __device__ __forceinline__ double owner_overflow_product(const OwnerArgs &a, int
         return owner_product_slow<FLAVOR>(a, (long long)e + i);
 }
 
+// Diagnostic builds only (make HIPFLAGS+=-DSMVP_PHASE_STAMPS): where a workgroup of the owner kernel spends its time.
+// Thread 0 of every workgroup adds the 100 MHz wall-clock ticks between its phase boundaries to six global counters;
+// smvp_debug_phase_stamps() (engine) prints and clears them.  The normal build contains none of this.
+#ifdef SMVP_PHASE_STAMPS
+__device__ unsigned long long g_owner_phase[8];
+#define SMVP_PHASE(n)                                                                        \
+    do {                                                                                     \
+        if (threadIdx.x == 0 && (blockIdx.x & 127) == 5) {                                   \
+            const unsigned long long now_ = wall_clock64();                                  \
+            if ((n) > 0)                                                                     \
+                atomicAdd(&g_owner_phase[(n)-1], now_ - phase_prev_);                        \
+            else                                                                             \
+                atomicAdd(&g_owner_phase[7], 1ull);                                          \
+            phase_prev_ = now_;                                                              \
+        }                                                                                    \
+    } while (0)
+#else
+#define SMVP_PHASE(n) do { } while (0)
+#endif
+
 template <int VPT, int FLAVOR, bool STAMPED>
 __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     const int *__restrict__ row_ptr, const int *__restrict__ col_ind, const double *__restrict__ val,
@@ -301,6 +322,9 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     __shared__ double wave_sum[kStreamBlock / 64];
 
     const int t = threadIdx.x;
+#ifdef SMVP_PHASE_STAMPS
+    unsigned long long phase_prev_ = 0;
+#endif
     // optional device-side timing: every wave notes when it started and (after its last store has been
     // acknowledged) when it finished; max(last) - min(first) over the launch is the product's own duration,
     // free of launch and event overhead (the engine reduces the slots, see stamp_reduce)
@@ -408,6 +432,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     const int rhi = tile_row[b + 1];
     if (rlo == rhi)
         SMVP_OWNER_EXIT();  // all of this tile continues a row owned by an earlier tile
+    SMVP_PHASE(0);
     const int lo = (int)s;  // nnz < 2^31
     const int e = (int)(s + TILE < (long long)nnz ? s + TILE : (long long)nnz);
     const int zend = tile_next[b];  // row_ptr[rhi]: end of the last owned row, >= e
@@ -418,7 +443,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     const bool over0 = !giant && t < ext;  // this lane fetches overflow entry e + t
     double p[VPT];
     double po = 0.0;
-    int rp_a = 0, rp_b = 0;
+    int rp_a = 0, rp_b = 0, rp_a2 = 0, rp_b2 = 0;  // bounds of this lane's first two rows of phase 2 (rlo + t, rlo + t + 256)
     int ovf_base = 0, cache0 = 0, in_place = 0;
     if constexpr (SORTED) {
         ovf_base = ex.ovf_ptr[b];
@@ -429,6 +454,10 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
         if (full_tile && rlo + t < rhi) {
             rp_a = row_ptr[rlo + t];
             rp_b = row_ptr[rlo + t + 1];
+        }
+        if (full_tile && rlo + t + kStreamBlock < rhi) {
+            rp_a2 = row_ptr[rlo + t + kStreamBlock];
+            rp_b2 = row_ptr[rlo + t + kStreamBlock + 1];
         }
         int co = 0, pjo = 0;
         if (over0) {
@@ -492,6 +521,10 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
             rp_a = row_ptr[rlo + t];
             rp_b = row_ptr[rlo + t + 1];
         }
+        if (rlo + t + kStreamBlock < rhi) {  // ... and its second: with short rows a tile holds more rows than lanes, and a
+            rp_a2 = row_ptr[rlo + t + kStreamBlock];  // row_ptr read behind the barrier is a whole memory round trip in phase 2
+            rp_b2 = row_ptr[rlo + t + kStreamBlock + 1];  // (in-kernel stamps on the near part of the random model, 4.3
+        }                                                 // entries per row: phase 2 took 4.1 of the workgroup's 9.9 us)
         int co = 0, pjo = 0;
         double vo = 0.0;
         if (over0) {
@@ -538,21 +571,32 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     if (!giant)  // rare: the last row runs more than one block width past the tile
         for (int i = t + kStreamBlock; i < ext; i += kStreamBlock)
             prod[e - lo + i] = owner_overflow_product<FLAVOR>(a, ovf_base, e, i);
+    SMVP_PHASE(1);
     __syncthreads();
+    SMVP_PHASE(2);
 
     // ---- phase 2b: one lane per owned row; its bounds were fetched with the tile (no global read after
     // the barrier for the first kStreamBlock rows); long rows are queued in LDS with their bounds
+    // Each lane's first two rows (their bounds came with the tile) are finished without touching memory in between: a
+    // row_ptr read in the same loop as the y stores made the compiler wait for vmcnt(0) every round, i.e. for the
+    // previous round's STORES to be acknowledged (CDNA4 counts stores in vmcnt) -- 3 of a workgroup's 10 us on short
+    // rows (in-kernel stamps).  Only a tile with more than 512 rows goes on to the loop that reads row_ptr.
     const int last = rhi - 1;
-    for (int r = rlo + t; r < rhi; r += kStreamBlock) {
-        if (giant && r == last)
-            continue;
-        const bool pre = full_tile && r == rlo + t;
-        const int ra = (pre ? rp_a : row_ptr[r]) - lo;
-        const int rz = (pre ? rp_b : row_ptr[r + 1]) - lo;
+    auto finish_row = [&](int r, int ra, int rz) {
         if (rz - ra <= kLongRow) {
+            // left to right, like the serial loop; the LDS reads go out four at a time, the adds stay in order
             double acc = 0.0;
-            for (int i = ra; i < rz; ++i)
-                acc += prod[i];
+            for (int i = ra; i < rz; i += 4) {
+                const double v0 = prod[i], v1 = prod[i + 1 < rz ? i + 1 : i], v2 = prod[i + 2 < rz ? i + 2 : i],
+                             v3 = prod[i + 3 < rz ? i + 3 : i];
+                acc += v0;
+                if (i + 1 < rz)
+                    acc += v1;
+                if (i + 2 < rz)
+                    acc += v2;
+                if (i + 3 < rz)
+                    acc += v3;
+            }
             __builtin_nontemporal_store(acc, &y[r]);
         } else {
             const int q = atomicAdd(&long_count, 1);
@@ -560,8 +604,24 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
             long_a[q] = ra;
             long_z[q] = rz;
         }
+    };
+    int r_next = rlo + t;
+    if (full_tile) {
+        if (r_next < rhi && !(giant && r_next == last))
+            finish_row(r_next, rp_a - lo, rp_b - lo);
+        r_next += kStreamBlock;
+        if (r_next < rhi && !(giant && r_next == last))
+            finish_row(r_next, rp_a2 - lo, rp_b2 - lo);
+        r_next += kStreamBlock;
     }
+    for (int r = r_next; r < rhi; r += kStreamBlock) {
+        if (giant && r == last)
+            continue;
+        finish_row(r, row_ptr[r] - lo, row_ptr[r + 1] - lo);
+    }
+    SMVP_PHASE(3);
     __syncthreads();
+    SMVP_PHASE(4);
 
     // ---- phase 2c: one wavefront per long row (measured: handing a long row to the finder's own wavefront
     // by ballot, without this queue and barrier, was 0-2 % slower -- the long rows of a tile then share one wave)
@@ -576,6 +636,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
         if (lane == 0)
             y[long_rows[q]] = acc;
     }
+    SMVP_PHASE(5);
 
     // ---- phase 2d: a last row that runs far past the tile: LDS part + the rest from global memory
     if (giant) {
@@ -932,6 +993,21 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
     return hipErrorInvalidValue;
 }
 
+#ifdef SMVP_PHASE_STAMPS
+void debug_owner_phases()
+{
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_owner_phase), sizeof h) != hipSuccess || h[7] == 0)
+        return;
+    const double n = (double)h[7];
+    fprintf(stderr, "[owner dbg] mean us per workgroup over %.0f: loads + gathers + LDS writes %.2f | barrier %.2f | lane-per-row sums %.2f | "
+                    "barrier %.2f | long rows %.2f\n", n, h[0] * 0.01 / n, h[1] * 0.01 / n, h[2] * 0.01 / n, h[3] * 0.01 / n, h[4] * 0.01 / n);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_owner_phase), z, sizeof z);
+}
+#else
+void debug_owner_phases() {}
+#endif
+
 hipError_t launch_stamp_reduce(const unsigned long long *stamps, int slots_per_product, int products,
                                unsigned long long *first_last, hipStream_t stream)
 {
@@ -1143,7 +1219,8 @@ __global__ __launch_bounds__(kSweepBlock) void csr_colsweep(
 // Chunks in flight per wavefront.  Strips of 2048 rows leave room for two workgroups per CU (64 KB of sums each):
 // two chunks in flight make up for the missing wavefronts (config 4: 2.25 against 2.55 ms; one rank's eighth
 // 0.44 against 0.50); shorter strips run more wavefronts per CU and do best with one (0.134 / 0.144 / 0.160 ms
-// for 1 / 2 / 4 on a 312 K-row chunk).  SMVP_SWEEP_G=1|2|4 overrides (development switch).
+// for 1 / 2 / 4 on a 312 K-row chunk).  SMVP_SWEEP_G=1|2|4 overrides (development switch).  Asked once per plan build (the
+// engine keeps the answer in the handle), never on a launch path.
 int sweep_chunks_in_flight(int strip_rows)
 {
     const char *env = getenv("SMVP_SWEEP_G");
@@ -1152,7 +1229,7 @@ int sweep_chunks_in_flight(int strip_rows)
 }
 
 hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, const double *e_val, const unsigned short *e_row,
-                               const double *x, double *y, int rows, int strip_rows, int per_launch, hipStream_t stream)
+                               const double *x, double *y, int rows, int strip_rows, int per_launch, int g, hipStream_t stream)
 {
     if (rows <= 0)
         return hipSuccess;
@@ -1161,7 +1238,6 @@ hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, con
     const size_t lds = sizeof(double) * (size_t)strip_rows * kSweepWaves;
     if (per_launch <= 0)
         per_launch = nwg;
-    const int g = sweep_chunks_in_flight(strip_rows);
     for (int first = 0; first < nwg; first += per_launch) {
         const unsigned grid = (unsigned)(nwg - first < per_launch ? nwg - first : per_launch);
 #define SMVP_SWEEP(GG)                                                                                                   \

@@ -20,6 +20,7 @@ OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_IO, ERR_UNSUPPORTED = 1, 2, 3, 4, 5, 6
 MM_COULD_NOT_READ_FILE, MM_PREMATURE_EOF, MM_NOT_MTX, MM_NO_HEADER, MM_UNSUPPORTED_TYPE = 11, 12, 13, 14, 15
 CSR_KERNEL_AUTO, CSR_KERNEL_VECTOR, CSR_KERNEL_STREAM, CSR_KERNEL_STREAM_CARRY, CSR_KERNEL_COLSWEEP = 0, 1, 2, 3, 4
+CSR_KERNEL_BINNED = 5
 MEM_HOST, MEM_DEVICE = 0, 1
 SYNTH_MEMPLUS_SHAPED, SYNTH_UNIFORM = 1, 2
 TJDS_MODE_AUTO, TJDS_MODE_ATOMIC, TJDS_MODE_TWO_PHASE, TJDS_MODE_ROW_GATHER = 0, 1, 2, 3
@@ -37,6 +38,10 @@ class RunOpts(C.Structure):
                 ("tjds_ref_quirks", C.c_int), ("convert_on_device", C.c_int), ("ngpus", C.c_int),
                 ("iterate", C.c_int), ("normalize", C.c_int), ("tjds_mode", C.c_int), ("timing", C.c_int),
                 ("x", C.c_void_p)]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("matrix_bytes", C.c_double), ("plan_bytes", C.c_double), ("build_ms", C.c_double)]
 
 
 class RunInfo(C.Structure):
@@ -66,7 +71,7 @@ EXPORTS = [
     "smvp_mm_read_header_path", "smvp_mm_read_coo_path", "smvp_mm_expanded_count", "smvp_mm_expand_symmetric",
     "smvp_cache_write_csr", "smvp_cache_read_header", "smvp_cache_read_csr", "smvp_coo_from_csr",
     "smvp_csr_from_coo", "smvp_tjds_from_coo", "smvp_csr_from_coo_device", "smvp_tjds_from_coo_device",
-    "smvp_device_count", "smvp_device_info",
+    "smvp_device_count", "smvp_device_info", "smvp_csr_plan_info", "smvp_tjds_plan_info",
     "smvp_csr_create", "smvp_csr_set_kernel", "smvp_csr_get_kernel", "smvp_csr_gather_spread", "smvp_csr_spmv",
     "smvp_csr_describe", "smvp_csr_plan_launches", "smvp_csr_destroy",
     "smvp_tjds_create", "smvp_tjds_set_x", "smvp_tjds_zero_y", "smvp_tjds_spmv",
@@ -98,6 +103,8 @@ def lib():
         L.smvp_csr_spmv.argtypes = [vp, vp, vp, vp]
         L.smvp_csr_describe.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double)]
         L.smvp_csr_plan_launches.argtypes = [vp, C.POINTER(ci)]
+        L.smvp_csr_plan_info.argtypes = [vp, C.POINTER(PlanInfo)]
+        L.smvp_tjds_plan_info.argtypes = [vp, C.POINTER(PlanInfo)]
         L.smvp_csr_destroy.argtypes = [vp]
         L.smvp_csr_destroy.restype = None
         L.smvp_tjds_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, ci, vp, vp, vp, vp, ci]
@@ -422,6 +429,12 @@ class CsrMatrix:
         _check(lib().smvp_csr_plan_launches(self._h, C.byref(n)), "smvp_csr_plan_launches")
         return n.value
 
+    def plan_info(self):
+        """{matrix_bytes, plan_bytes, build_ms} of the current launch plan."""
+        i = PlanInfo()
+        _check(lib().smvp_csr_plan_info(self._h, C.byref(i)), "smvp_csr_plan_info")
+        return {"matrix_bytes": i.matrix_bytes, "plan_bytes": i.plan_bytes, "build_ms": i.build_ms}
+
     def gather_spread(self):
         """Share of the gathers that pull their own line of x (what AUTO's choice of the column sweep rests on); -1: not sampled."""
         v = C.c_double()
@@ -433,9 +446,9 @@ class CsrMatrix:
         _check(lib().smvp_csr_spmv(self._h, _dev_ptr(x), _dev_ptr(y), _stream_ptr(stream)), "smvp_csr_spmv")
 
     def describe(self):
-        name = C.create_string_buffer(128)
+        name = C.create_string_buffer(256)
         b = C.c_double()
-        _check(lib().smvp_csr_describe(self._h, name, 128, C.byref(b)), "smvp_csr_describe")
+        _check(lib().smvp_csr_describe(self._h, name, 256, C.byref(b)), "smvp_csr_describe")
         return name.value.decode(), b.value
 
     def close(self):
@@ -491,6 +504,12 @@ class TjdsMatrix:
         m, n = C.c_int(), C.c_longlong()
         _check(lib().smvp_tjds_get_value_cache(self._h, C.byref(m), C.byref(n)), "smvp_tjds_get_value_cache")
         return m.value, n.value
+
+    def plan_info(self):
+        """{matrix_bytes, plan_bytes, build_ms}: the plans of the modes selected so far."""
+        i = PlanInfo()
+        _check(lib().smvp_tjds_plan_info(self._h, C.byref(i)), "smvp_tjds_plan_info")
+        return {"matrix_bytes": i.matrix_bytes, "plan_bytes": i.plan_bytes, "build_ms": i.build_ms}
 
     def set_ref_quirks(self, enable=True):
         _check(lib().smvp_tjds_set_ref_quirks(self._h, int(enable), self._t.ref_num_tjdiag,

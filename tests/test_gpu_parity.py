@@ -29,7 +29,8 @@ EXACT = {"ibm32.mtx", "curtis54.mtx", "pwt.mtx", "pdp08-pg4.mtx"}
 CSR_VARIANTS = [(sm.CSR_KERNEL_STREAM, 256), (sm.CSR_KERNEL_STREAM, 1024), (sm.CSR_KERNEL_STREAM, 2048),
                 (sm.CSR_KERNEL_STREAM_CARRY, 1024), (sm.CSR_KERNEL_STREAM_CARRY, 2048)] + \
                [(sm.CSR_KERNEL_VECTOR, t) for t in (2, 4, 8, 16, 32, 64)] + \
-               [(sm.CSR_KERNEL_COLSWEEP, rb) for rb in (0, 1024, 8192)]
+               [(sm.CSR_KERNEL_COLSWEEP, rb) for rb in (0, 1024, 8192)] + \
+               [(sm.CSR_KERNEL_BINNED, band) for band in (0, 1, 3, 100)]   # band: |column - row| beyond it is "far"
 
 
 @pytest.fixture(scope="module")
@@ -261,11 +262,112 @@ def test_colsweep_rows_that_meet_in_a_chunk(torch):
         assert np.array_equal(y, ref)
 
 
+def test_binned_plan_on_the_random_model(torch):
+    """SURVEY 8(d)'s memplus-shaped random model (2^22 rows here): AUTO picks the binned plan -- near part on the tile
+    kernel, far part through the LDS-binned passes; the result is within the normwise bound of the serial loop, the
+    same bits from run to run, equal to the serial loop's bits on every short row without far entries; the plan's
+    size is what smvp_csr_plan_info says."""
+    rows = 1 << 22
+    row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_MEMPLUS_SHAPED, 12345, rows, rows)
+    x = sm.vector_random(rows)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+    scale = row_scale(row_ptr, col_ind, val, x)
+    A = sm.CsrMatrix(rows, rows, row_ptr, col_ind, val)
+    assert A.get_kernel() == (sm.CSR_KERNEL_BINNED, 4096) and A.launches() == 3
+    name, alg = A.describe()
+    assert name.startswith("csr_binned: csr_stream_owner<") and "csr_binned_far_products" in name and "csr_binned_far_sums" in name
+    assert alg == 12.0 * len(val) + 4.0 * (rows + 1) + 16.0 * rows
+    dx = dev(torch, x)
+    ys = []
+    for _ in range(3):
+        dy = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+        A.spmv(dx, dy)
+        torch.cuda.synchronize()
+        ys.append(dy.cpu().numpy())
+    assert_close(ys[0], ref, scale)
+    assert np.array_equal(ys[0], ys[1]) and np.array_equal(ys[0], ys[2])
+    rows_of = np.repeat(np.arange(rows), np.diff(row_ptr))
+    far = np.abs(col_ind.astype(np.int64) - rows_of) > 4096
+    has_far = np.bincount(rows_of[far], minlength=rows) > 0
+    short = np.diff(row_ptr) <= 32
+    assert 0.3 < far.mean() < 0.5 and (short & ~has_far).sum() > 1000
+    assert np.array_equal(ys[0][short & ~has_far], ref[short & ~has_far])
+    info = A.plan_info()
+    n, nf = len(val), int(far.sum())
+    assert info["matrix_bytes"] == 12.0 * n + 4.0 * (rows + 1)
+    # near copy 12 B (+ 2 B of column offsets) per near entry, 20 B per far entry (two streams + the bins), 16 B per far row
+    assert 12.0 * (n - nf) + 20.0 * nf < info["plan_bytes"] < 14.5 * (n - nf) + 21.0 * nf + 24.0 * rows and info["build_ms"] > 0
+    # the tile kernel on the same handle: the same product
+    A.set_kernel(sm.CSR_KERNEL_STREAM, 0)
+    dy = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+    A.spmv(dx, dy)
+    torch.cuda.synchronize()
+    assert_close(dy.cpu().numpy(), ref, scale)
+    assert A.plan_info()["plan_bytes"] < 3.0 * n
+    # other bands, ones as the operand (the reference's), and back to AUTO
+    for band in (64, 1 << 20):
+        A.set_kernel(sm.CSR_KERNEL_BINNED, band)
+        assert A.get_kernel() == (sm.CSR_KERNEL_BINNED, band)
+        dy.fill_(float("nan"))
+        A.spmv(dx, dy)
+        torch.cuda.synchronize()
+        assert_close(dy.cpu().numpy(), ref, scale)
+    A.set_kernel(sm.CSR_KERNEL_AUTO, 0)
+    assert A.get_kernel() == (sm.CSR_KERNEL_BINNED, 4096)
+    ones = np.ones(rows)
+    dy.fill_(float("nan"))
+    A.spmv(dev(torch, ones), dy)
+    torch.cuda.synchronize()
+    assert_close(dy.cpu().numpy(), ob.csr_spmv(row_ptr, col_ind, val, ones), row_scale(row_ptr, col_ind, val, ones))
+    A.close()
+
+
+def test_binned_plan_corner_structures(torch):
+    """The binned plan where its bookkeeping is stressed: far rows longer than a wavefront's 32 (summed by a whole
+    wavefront) and longer than the cap of 1024 (kept near), rows with only far / only near entries, empty rows, more
+    column blocks than a workgroup stages shifts for, duplicate and unsorted columns, a rectangular matrix."""
+    rng = np.random.default_rng(2024)
+    # wide: 3 M columns = 184 column blocks; rows of 0 ... 1500 entries, a few of them duplicates, columns NOT sorted
+    rows, cols = 6000, 3_000_000
+    lens = np.where(rng.random(rows) < 0.05, rng.integers(500, 1500, rows), rng.integers(0, 40, rows))
+    lens[:3] = (0, 1, 33)
+    row_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col_ind = rng.integers(0, cols, int(row_ptr[-1])).astype(np.int32)
+    idx = np.arange(0, len(col_ind) - 1, 97)
+    col_ind[idx] = col_ind[idx + 1]                               # some repeats (mostly inside rows)
+    val = rng.uniform(-1, 1, len(col_ind))
+    x = rng.random(cols)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+    scale = row_scale(row_ptr, col_ind, val, x)
+    for band in (0, 5, 2_000_000):
+        y = gpu_csr(torch, rows, cols, row_ptr, col_ind, val, x, sm.CSR_KERNEL_BINNED, band)
+        assert_close(y, ref, scale)
+    # tall and narrow: every column within a few blocks, many far rows per row block, rows == 0 far entries in stretches
+    rows, cols = 200_000, 40_000
+    lens = rng.integers(0, 9, rows)
+    lens[50_000:90_000] = 0
+    row_ptr, col_ind, val = csr_from_lengths(rng, lens.tolist(), cols)
+    x = rng.random(cols)
+    y = gpu_csr(torch, rows, cols, row_ptr, col_ind, val, x, sm.CSR_KERNEL_BINNED, 16)
+    assert_close(y, ob.csr_spmv(row_ptr, col_ind, val, x), row_scale(row_ptr, col_ind, val, x))
+
+
+@pytest.mark.parametrize("kernel,param", CSR_VARIANTS)
+def test_csr_matrix_without_rows(torch, kernel, param):
+    """rows == 0 (the sharded layer makes such handles for empty chunks): every family plans and launches nothing."""
+    A = sm.CsrMatrix(0, 7, np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    A.set_kernel(kernel, param)
+    assert A.get_kernel()[0] == kernel
+    A.spmv(torch.ones(7, dtype=torch.float64, device="cuda"), torch.zeros(1, dtype=torch.float64, device="cuda"))
+    torch.cuda.synchronize()
+    A.close()
+
+
 def test_auto_plan_choice(torch):
     """AUTO: owner-completes tiles by default, the carry form when some row is extremely long; never the vector kernel;
     the column sweep only for large matrices whose gathers scatter over an operand much larger than the L2."""
     # a band of 8 entries per row, 32 M entries over a 32 MB operand: neighbouring gathers share lines -> tile kernel;
-    # the SURVEY 8(d) random model (39 % of its entries uniform over the operand: spread about 0.4) -> tile kernel
+    # the SURVEY 8(d) random model (39 % of its entries uniform over the operand: spread about 0.4) -> the binned plan
     n = 4_000_000
     band = ((np.arange(n, dtype=np.int64)[:, None] + np.arange(-4, 4)) % n).astype(np.int32)
     band.sort(axis=1)
@@ -274,7 +376,7 @@ def test_auto_plan_choice(torch):
     A.close()
     row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_MEMPLUS_SHAPED, 5, 1 << 22, 1 << 22)
     A = sm.CsrMatrix(1 << 22, 1 << 22, row_ptr, col_ind, val)
-    assert A.get_kernel()[0] == sm.CSR_KERNEL_STREAM
+    assert A.get_kernel() == (sm.CSR_KERNEL_BINNED, 4096) and 0.2 <= A.gather_spread() < 0.6
     A.close()
     rng = np.random.default_rng(11)
     for lens, want in (([5] * 300000, sm.CSR_KERNEL_STREAM), ([3] * 500 + [40000] + [2] * 500, sm.CSR_KERNEL_STREAM_CARRY),
@@ -674,12 +776,17 @@ def test_big_synthetic_properties(torch, big):
     k = 100_000
     sub = ob.csr_spmv(row_ptr[:k + 1].copy(), col_ind[:row_ptr[k]], val[:row_ptr[k]], xa.cpu().numpy())
     assert np.all(np.abs(ya.cpu().numpy()[:k] - sub) <= TOL * 2 * scale[:k])
-    # (5) idempotence: the same launch twice gives the same bits (no atomics on the CSR path)
-    A.set_kernel(sm.CSR_KERNEL_STREAM, 0)
+    # (5) idempotence: the same launch twice gives the same bits (no atomics on the CSR path) -- the plan AUTO picks for
+    # this matrix (the binned one) and the tile kernel each repeat themselves; between them the normwise bound holds
     y2 = torch.empty_like(ya)
-    A.spmv(xa, y2)
-    torch.cuda.synchronize()
-    assert torch.equal(ya, y2)
+    for kernel in (sm.CSR_KERNEL_AUTO, sm.CSR_KERNEL_STREAM):
+        A.set_kernel(kernel, 0)
+        A.spmv(xa, y2)
+        y3 = torch.empty_like(ya)
+        A.spmv(xa, y3)
+        torch.cuda.synchronize()
+        assert torch.equal(y2, y3)
+        assert torch.equal(ya, y2) if kernel == sm.CSR_KERNEL_AUTO else bool(((ya - y2).abs() <= TOL * sc).all())
     A.close()
 
 
@@ -1409,10 +1516,14 @@ def test_device_timing_agrees_with_events_and_is_the_default_for_small_launches(
     rng = np.random.default_rng(5)
     rows = 2_500_000                                                            # 5 M entries = 4883 tiles of 1024
     coo_big = sm.make_coo(np.repeat(np.arange(rows), 2), rng.integers(0, rows, 2 * rows), rng.random(2 * rows))
-    sm.csr_compute(coo_big, rows, rows, iters=3)
+    y_auto, _, _ = sm.csr_compute(coo_big, rows, rows, iters=3)                 # (AUTO: scattered far columns -> the binned plan)
     assert sm.last_run_info().timing == sm.TIMING_EVENTS
-    sm.csr_compute(coo_big, rows, rows, iters=3, timing=sm.TIMING_DEVICE)      # but can be asked for
+    y_tile, _, _ = sm.csr_compute(coo_big, rows, rows, iters=3, kernel=sm.CSR_KERNEL_STREAM)
+    assert sm.last_run_info().timing == sm.TIMING_EVENTS and np.allclose(y_auto, y_tile, rtol=0, atol=1e-12)
+    sm.csr_compute(coo_big, rows, rows, iters=3, kernel=sm.CSR_KERNEL_STREAM, timing=sm.TIMING_DEVICE)   # but can be asked for
     assert sm.last_run_info().timing == sm.TIMING_DEVICE
+    with pytest.raises(sm.SmvpError):                                           # not of a product of several launches
+        sm.csr_compute(coo_big, rows, rows, iters=3, kernel=sm.CSR_KERNEL_BINNED, timing=sm.TIMING_DEVICE)
     with pytest.raises(sm.SmvpError):                                           # not with a changing operand
         sm.csr_compute(coo, m, n, iters=3, iterate=True, timing=sm.TIMING_DEVICE)
 
