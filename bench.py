@@ -70,7 +70,10 @@ def parse():
     ap.add_argument("--no-samples", action="store_true", help="skip extra.sample_matrices (BASELINE configs 2, 3, 5)")
     ap.add_argument("--no-config4", action="store_true", help="skip extra.config4 (10 M x 32/row, every N)")
     ap.add_argument("--no-pwt-tiled", action="store_true", help="skip extra.pwt_tiled (N = 1)")
-    ap.add_argument("--chunks", type=int, default=4, help="config 4, N > 1: row chunks per rank for the overlapped all-gather")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="config 4, N > 1: row chunks per rank for the overlapped all-gather (0 = chosen from this run's own "
+                         "measurements of 1 / 2 / 4 chunks, sharding.choose_chunks)")
+    ap.add_argument("--no-eighth", action="store_true", help="config 4, N = 1: skip the 1 / 2 / 4-chunk timing of one rank's share at N = 8")
     ap.add_argument("--config4-kernel", default="auto", choices=["auto", "colsweep", "tile"],
                     help="config 4: kernel of the step timings (auto = what the library picks: the column sweep; the tile "
                          "kernel's product time is reported either way)")
@@ -80,6 +83,9 @@ def parse():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic in this run (rocprofv3 --pmc child passes); fall back to profiles/")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the inner run of a --pmc child pass
+    ap.add_argument("--c-layer-child", type=int, default=0, help=argparse.SUPPRESS)   # child process: the C layer alone on this many GPUs
+    ap.add_argument("--c-layer-budget", type=float, default=240.0,
+                    help="N > 1: wall-clock seconds the C-layer leg (a child process of rank 0) may take before it is given up")
     ap.add_argument("--cpu-iters", type=int, default=0, help="0 = sized for about 15 s")
     ap.add_argument("--no-allgather", action="store_true", help="N > 1: time the local products only")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
@@ -216,6 +222,9 @@ def measure_csr(torch, dist, sm, sharding_mod, blk, args, world, local_rank, ran
         del d_coo
     kernel_name, alg_bytes = A.describe()
     launches = A.launches() if fmt == "csr" else 1
+    pi = A.plan_info()
+    plan = {"plan_bytes": pi["plan_bytes"], "matrix_bytes": pi["matrix_bytes"],
+            "plan_over_matrix": round(pi["plan_bytes"] / max(1.0, pi["matrix_bytes"]), 3), "plan_build_ms": round(pi["build_ms"], 1)}
 
     x_host = np.ones(blk["cols_total"]) if args.x == "ones" else np.random.default_rng(67890).random(blk["cols_total"])
     d_x = torch.from_numpy(x_host).cuda()
@@ -290,9 +299,28 @@ def measure_csr(torch, dist, sm, sharding_mod, blk, args, world, local_rank, ran
     if world > 1:
         dist.all_reduce(tot)
     res = dict(kernel=kernel_name, launches=launches, alg_bytes_local=alg_bytes, alg_bytes_total=float(tot[1]), nnz_total=float(tot[0]),
-               wall_per_step=wall / steps, kernel_ms=k_ms / steps, worst=worst, golden=golden, scale=scale, got=got,
+               wall_per_step=wall / steps, kernel_ms=k_ms / steps, worst=worst, golden=golden, scale=scale, got=got, plan=plan,
                x_host=x_host, d_x=d_x, d_y=d_y, A=A, keep=(d_row_ptr, d_col_ind, d_val, d_y_full))
     return res
+
+
+def _config4_block(torch, sm, rows, ranges, local_rank, threads):
+    """CSR handles of the row ranges `ranges` of BASELINE config 4 (one per chunk) + what checks them on the host."""
+    mats, nnz_local, alg_local, checks = [], 0, 0.0, []
+    for r0, r1 in ranges:
+        rp, ci, v = sm.synth_csr(sm.SYNTH_UNIFORM, 2024, rows, rows, 32, r0, r1, threads=threads)
+        A = sm.CsrMatrix(r1 - r0, rows, torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(v).cuda(),
+                         device=local_rank)
+        n = int(rp[-1])
+        nnz_local += n
+        alg_local += 12.0 * n + 4.0 * (r1 - r0 + 1) + 8.0 * (r1 - r0)     # x is counted once per rank, by the caller, not once per chunk
+        # x = ones (the reference's operand): y = the row sums of val, computed independently on the host
+        host = np.add.reduceat(v, rp[:-1]) if n else np.zeros(r1 - r0)
+        scale = np.add.reduceat(np.abs(v), rp[:-1]) if n else np.zeros(r1 - r0)
+        checks.append((r0, r1, host, scale))
+        mats.append(A)
+        del rp, ci, v
+    return mats, nnz_local, alg_local + 8.0 * rows, checks
 
 
 def measure_config4(torch, dist, sm, sharding_mod, args, world, local_rank, rank, steps):
@@ -301,40 +329,61 @@ def measure_config4(torch, dist, sm, sharding_mod, args, world, local_rank, rank
     Row ownership is block-cyclic (sharding.cyclic_chunk_rows): every rank holds `chunks` row chunks, each its own CSR
     handle; the all-gather of chunk c lands as one contiguous run of the full y.  Three timings, all max over ranks:
     local products only; products, then the all-gathers (nothing overlapped); each chunk's all-gather issued
-    asynchronously behind its product (chunk c travels while chunk c+1 is multiplied).
+    asynchronously behind its product (chunk c travels while chunk c+1 is multiplied).  The chunk count is not a
+    constant: the column sweep pays for every chunk (each pulls all of x into the L2s again), so it is chosen from this
+    run's own measurements (sharding.choose_chunks) unless --chunks names it.  The same keys at every N: t1_ms (the
+    whole matrix on ONE GPU, measured in this run), tN_step_ms, speedup_overlapped, speedup_after.
     """
     rows = args.rows
-    chunks = max(1, args.chunks) if (world > 1 or dist.is_initialized()) else 1   # SMVP_FORCE_DIST rehearses the chunked path with one rank
-    t0 = time.perf_counter()
-    ex = sharding_mod.ChunkedExchange(torch, dist, rows, world, rank, chunks, "cuda")
+    gather = world > 1 or dist.is_initialized()     # SMVP_FORCE_DIST rehearses the chunked path with one rank
     threads = max(1, min(64, (os.cpu_count() or 8) // max(1, world)))
-    mats, nnz_local, alg_local, checks = [], 0, 0.0, []
-    for c, (r0, r1) in enumerate(ex.ranges):
-        rp, ci, v = sm.synth_csr(sm.SYNTH_UNIFORM, 2024, rows, rows, 32, r0, r1, threads=threads)
-        A = sm.CsrMatrix(r1 - r0, rows, torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(v).cuda(),
-                         device=local_rank)
-        n = int(rp[-1])
-        nnz_local += n
-        alg_local += 12.0 * n + 4.0 * (r1 - r0 + 1) + 8.0 * (r1 - r0)     # x is counted once per rank, below, not once per chunk
-        # x = ones (the reference's operand): y = the row sums of val, computed independently on the host
-        host = np.add.reduceat(v, rp[:-1]) if n else np.zeros(r1 - r0)
-        scale = np.add.reduceat(np.abs(v), rp[:-1]) if n else np.zeros(r1 - r0)
-        checks.append((r0, r1, host, scale))
-        mats.append(A)
-        del rp, ci, v
-    alg_local += 8.0 * rows        # SURVEY 8(d): 12 nnz_local + 4 (M_local + 1) + 8 N + 8 M_local per rank, whatever the chunking
-    kname = mats[0].describe()[0]
-    log(rank, "config 4: rows %d, %d chunk(s) per rank, %d local entries, built in %.1f s" % (rows, chunks, nnz_local,
-                                                                                             time.perf_counter() - t0))
     d_x = torch.ones(rows, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream()
+
+    def time_products(ex, mats, n):
+        def product(c, out):
+            r0, r1 = ex.ranges[c]
+            if r1 > r0:
+                mats[c].spmv(d_x, out, stream=stream)
+        for _ in range(2):
+            ex.step(product, overlap=False, gather=False)
+        _, ev = timed_region(torch, dist, world, n, lambda: ex.step(product, overlap=False, gather=False))
+        return ev / n
+
+    # ---- how many chunks per rank
+    if args.chunks > 0 or not gather:
+        chunks = max(1, args.chunks) if gather else 1
+        choice = {"chosen": chunks, "rule": "--chunks %d" % args.chunks if gather else "one GPU, no exchange: one chunk"}
+    else:
+        product_ms, gather_ms = {}, {}
+        for c in (1, 2, 4):
+            ex = sharding_mod.ChunkedExchange(torch, dist, rows, world, rank, c, "cuda")
+            mats, _, _, _ = _config4_block(torch, sm, rows, ex.ranges, local_rank, threads)
+            product_ms[c] = time_products(ex, mats, max(3, steps // 4))
+            for _ in range(2):
+                ex._gather(0, False)
+            _, ev = timed_region(torch, dist, world, max(3, steps // 4), lambda: ex._gather(0, False))
+            gather_ms[c] = ev / max(3, steps // 4)
+            for A in mats:
+                A.close()
+            del mats, ex
+            torch.cuda.empty_cache()
+        choice = sharding_mod.choose_chunks(product_ms, 8.0 * rows / world, world, gather_ms)
+        chunks = choice["chosen"]
+        log(rank, "config 4: chunks per rank chosen from this run's measurements: %s" % json.dumps(choice))
+
+    t0 = time.perf_counter()
+    ex = sharding_mod.ChunkedExchange(torch, dist, rows, world, rank, chunks, "cuda")
+    mats, nnz_local, alg_local, checks = _config4_block(torch, sm, rows, ex.ranges, local_rank, threads)
+    kname = mats[0].describe()[0]
+    plan = [A.plan_info() for A in mats]
+    log(rank, "config 4: rows %d, %d chunk(s) per rank, %d local entries, built in %.1f s" % (rows, chunks, nnz_local,
+                                                                                             time.perf_counter() - t0))
 
     def product(c, out):
         r0, r1 = ex.ranges[c]
         if r1 > r0:
             mats[c].spmv(d_x, out, stream=stream)
-
-    gather = world > 1 or dist.is_initialized()
 
     def check():
         y_full = ex.step(product, overlap=True, gather=gather)
@@ -403,15 +452,19 @@ def measure_config4(torch, dist, sm, sharding_mod, args, world, local_rank, rank
     nnz, alg = float(tot[0]), float(tot[1])
     out = {"workload": "uniform 32 entries/row rows=%d seed=2024 (BASELINE config 4)" % rows, "rows": rows, "nnz": int(nnz),
            "n_gpus": world, "kernel": kname, "kernel_choice": args.config4_kernel,
-           "auto_picks": {1: "vector", 2: "tile (stream)", 3: "tile (stream-carry)", 4: "column sweep"}.get(auto_kernel[0]),
+           "auto_picks": {1: "vector", 2: "tile (stream)", 3: "tile (stream-carry)", 4: "column sweep", 5: "binned"}.get(auto_kernel[0]),
            "rows_per_workgroup": mats[0].get_kernel()[1], "launches_per_product": launches,
-           "gather_spread_estimate": round(spread, 3), "chunks_per_rank": chunks, "steps": steps,
+           "gather_spread_estimate": round(spread, 3), "chunks_per_rank": chunks, "chunks_chosen": chunks, "chunk_choice": choice,
+           "steps": steps,
            "spmv_only_ms": round(best_ms, 4), "spmv_only_GFLOPs": round(2.0 * nnz / best_ms * 1e-6, 1),
            "max_normwise_error_vs_host": worst, "bit_identical_run_to_run": True, "bit_identical_to_tile_kernel": True,
            "x_gathers_per_second_G_per_gpu": round(nnz / best_ms * 1e-6 / world, 1),
            "tile_kernel_spmv_only_ms": round(tile_ms, 4), "tile_kernel_GFLOPs": round(2.0 * nnz / tile_ms * 1e-6, 1),
            "tile_kernel_x_gathers_per_second_G_per_gpu": round(nnz / tile_ms * 1e-6 / world, 1),
            "alg_bytes_per_product": alg,
+           "plan": {"plan_bytes_local": sum(p["plan_bytes"] for p in plan), "matrix_bytes_local": sum(p["matrix_bytes"] for p in plan),
+                    "plan_over_matrix": round(sum(p["plan_bytes"] for p in plan) / max(1.0, sum(p["matrix_bytes"] for p in plan)), 3),
+                    "plan_build_ms": round(sum(p["build_ms"] for p in plan), 1)},
            "note": "uniform columns over an 80 MB x: with the tile kernel every x gather misses L2 and one GPU is bound by "
                    "its L2-miss gather rate (about 54 G/s, tools/gather_bench.hip), not by HBM bytes; the column-swept "
                    "kernel (AUTO's choice here; same bits as the serial loop) slides one L2-sized window over x"}
@@ -419,6 +472,7 @@ def measure_config4(torch, dist, sm, sharding_mod, args, world, local_rank, rank
         out["frac_of_hbm_peak"] = round(alg / best_ms * 1e-6 / HBM_PEAK_GBS, 4)
         out["achieved_GBps"] = round(alg / best_ms * 1e-6, 1)
         out["tile_kernel_frac_of_hbm_peak"] = round(alg / tile_ms * 1e-6 / HBM_PEAK_GBS, 4)
+    plain_ms = over_ms = best_ms
     if gather:
         plain_ms, _ = run(False, True)
         over_ms, _ = run(True, True)
@@ -429,6 +483,63 @@ def measure_config4(torch, dist, sm, sharding_mod, args, world, local_rank, rank
                             os.environ.get("SMVP_DIST_BACKEND", "nccl = RCCL over xGMI"))
     for A in mats:
         A.close()
+    del mats, ex
+    torch.cuda.empty_cache()
+
+    # ---- the same keys at every N: the whole matrix on ONE GPU (t1_ms) against this N's step
+    t1_ms = best_ms
+    if world > 1:
+        # rank 0 multiplies the whole matrix alone (3.8 GB + its plan fit one GPU) while the others wait at the barrier
+        if rank == 0:
+            ex1 = sharding_mod.ChunkedExchange(torch, dist, rows, 1, 0, 1, "cuda")
+            m1, _, _, _ = _config4_block(torch, sm, rows, ex1.ranges, local_rank, max(1, min(64, os.cpu_count() or 8)))
+            for _ in range(2):
+                m1[0].spmv(d_x, ex1.local(0), stream=stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                m1[0].spmv(d_x, ex1.local(0), stream=stream)
+            e1.record()
+            torch.cuda.synchronize()
+            t1_ms = e0.elapsed_time(e1) / steps
+            m1[0].close()
+            del m1, ex1
+            torch.cuda.empty_cache()
+        t = torch.tensor([t1_ms if rank == 0 else 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t1_ms = float(t[0])
+    out.update(t1_ms=round(t1_ms, 4), tN_step_ms=round(over_ms, 4), tN_step_after_ms=round(plain_ms, 4),
+               tN_products_only_ms=round(best_ms, 4),
+               speedup_overlapped=round(t1_ms / over_ms, 3), speedup_after=round(t1_ms / plain_ms, 3),
+               speedup_products_only=round(t1_ms / best_ms, 3))
+
+    # ---- N = 1: what one rank of eight would hold, cut into 1 / 2 / 4 chunks, measured here; the chunk count the model picks
+    if world == 1 and not gather and not getattr(args, "no_eighth", False):
+        try:
+            product_ms = {}
+            for c in (1, 2, 4):
+                ranges = sharding_mod.cyclic_chunk_rows(rows, 8, c)[1][0]
+                m8, _, _, _ = _config4_block(torch, sm, rows, ranges, local_rank, threads)
+                bufs = [torch.empty(max(1, r1 - r0), dtype=torch.float64, device="cuda") for r0, r1 in ranges]
+
+                def eighth():
+                    for A, buf, (r0, r1) in zip(m8, bufs, ranges):
+                        if r1 > r0:
+                            A.spmv(d_x, buf, stream=stream)
+                for _ in range(3):
+                    eighth()
+                _, ev = timed_region(torch, dist, 1, steps, eighth)
+                product_ms[c] = ev / steps
+                for A in m8:
+                    A.close()
+                del m8, bufs
+                torch.cuda.empty_cache()
+            out["eighth_of_n8"] = sharding_mod.choose_chunks(product_ms, 8.0 * rows / 8, 8)
+            out["eighth_of_n8"]["what"] = ("rank 0's share at N = 8 (block-cyclic, %d rows) multiplied on this one GPU as 1 / 2 / 4 chunks; "
+                                           "the all-gather priced by the two link models (no second GPU here)" % (rows // 8))
+            out["chunks_chosen_for_n8"] = out["eighth_of_n8"]["chosen"]
+        except Exception as e:
+            out["eighth_of_n8"] = {"error": str(e)}
     return out
 
 
@@ -495,6 +606,7 @@ def measure_pwt_tiled(torch, dist, sm, sharding_mod, local_rank, rank, steps):
     rows, cols, nnz = m * copies, n * copies, int(RP[-1])
     A = sm.CsrMatrix(rows, cols, torch.from_numpy(RP).cuda(), torch.from_numpy(CI).cuda(), torch.from_numpy(V).cuda(), device=local_rank)
     kname, alg = A.describe()
+    api = A.plan_info()
     d_x = torch.ones(cols, dtype=torch.float64, device="cuda")
     d_y = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream()
@@ -515,7 +627,9 @@ def measure_pwt_tiled(torch, dist, sm, sharding_mod, local_rank, rank, steps):
            "rows": rows, "nnz": nnz, "kernel": kname, "ms_per_launch": round(ms, 5), "alg_bytes_per_product": alg,
            "GFLOPs": round(2.0 * nnz / ms * 1e-6, 1),
            "achieved_GBps": round(alg / ms * 1e-6, 1), "frac_of_hbm_peak": round(alg / ms * 1e-6 / HBM_PEAK_GBS, 4),
-           "y_equals_tiled_reference_pwt_y": True}
+           "y_equals_tiled_reference_pwt_y": True,
+           "plan": {"plan_bytes": api["plan_bytes"], "matrix_bytes": api["matrix_bytes"],
+                    "plan_over_matrix": round(api["plan_bytes"] / max(1.0, api["matrix_bytes"]), 3), "plan_build_ms": round(api["build_ms"], 1)}}
     A.close()
     coo2 = np.zeros(nnz, dtype=sm.COO_DTYPE)
     coo2["row"] = np.repeat(np.arange(rows, dtype=np.int32), np.diff(RP))
@@ -531,10 +645,14 @@ def measure_pwt_tiled(torch, dist, sm, sharding_mod, local_rank, rank, steps):
     if not torch.equal(d_yt, d_y):
         raise SystemExit("pwt x%d: TJDS differs from CSR" % copies)
     tname, tbytes = T.describe()
+    tpi = T.plan_info()
     _, tms = timed_region(torch, dist, 1, steps, lambda: T.spmv(d_yt, stream=stream))
     tms /= steps
     out["tjds"] = {"kernel": tname, "ms_per_step": round(tms, 5), "alg_bytes_per_product": tbytes, "GFLOPs": round(2.0 * nnz / tms * 1e-6, 1),
-                   "frac_of_hbm_peak": round(tbytes / tms * 1e-6 / HBM_PEAK_GBS, 4), "equals_csr_bit_for_bit": True}
+                   "frac_of_hbm_peak": round(tbytes / tms * 1e-6 / HBM_PEAK_GBS, 4), "equals_csr_bit_for_bit": True,
+                   "plan": {"plan_bytes": tpi["plan_bytes"], "matrix_bytes": tpi["matrix_bytes"],
+                            "plan_over_matrix": round(tpi["plan_bytes"] / max(1.0, tpi["matrix_bytes"]), 3),
+                            "plan_build_ms": round(tpi["build_ms"], 1)}}
     T.close()
     return out
 
@@ -630,8 +748,13 @@ def measure_c_layer(sm, rows, ngpus, steps, rank):
     out = {"workload": "uniform 32 entries/row rows=%d seed=2024 (BASELINE config 4)" % rows, "n_gpus": ngpus, "nnz": nnz, "steps": steps,
            "what": "smvp_sharded_spmv (C ABI, one process drives all GPUs; row blocks balanced by entries, each cut into row "
                    "chunks; RCCL all-gather of y per chunk)"}
+    # fewer GPUs than ranks (a rehearsal on one GPU): the ranks share them and the y blocks travel by device-to-device copies
+    virtual = ngpus > sm.device_count()
+    out["exchange"] = "device-to-device copies between virtual ranks (rehearsal: %d ranks on %d GPU(s))" % (ngpus, sm.device_count()) \
+        if virtual else "RCCL ncclAllGather, one communicator rank per GPU"
     for chunks in (1, 4):
-        S = sm.ShardedMatrix("csr", ngpus, rows, rows, csr=(rp, ci, v), chunks=chunks)
+        S = sm.ShardedMatrix("csr", ngpus, rows, rows, csr=(rp, ci, v), chunks=chunks,
+                             exchange=sm.EXCHANGE_COPIES if virtual else sm.EXCHANGE_RCCL)
         S.set_x(None)
         S.spmv(allgather=sm.GATHER_OVERLAPPED)
         S.synchronize()
@@ -663,13 +786,51 @@ def measure_c_layer(sm, rows, ngpus, steps, rank):
     return out
 
 
+def c_layer_in_child(args, ngpus, steps, rank):
+    """N > 1: the C ABI's sharded product (one process driving every GPU) runs in a CHILD of rank 0, started before rank 0
+    -- or any other rank: they wait on a file -- has touched a GPU, under a wall-clock budget: the layer has never run
+    on more than one GPU, and a hang inside it (RCCL among the GPUs of one process) must cost this leg, not the run."""
+    import signal
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--c-layer-child", str(ngpus), "--rows", str(args.rows), "--steps", str(steps)]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")
+           and not k.startswith("TORCHELASTIC")}
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    except Exception as e:
+        return {"error": "could not start the child: %s" % e}
+    try:
+        out, err = p.communicate(timeout=args.c_layer_budget)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)      # the process group this child was started as
+        except Exception:
+            pass
+        try:
+            p.communicate(timeout=10)
+        except Exception:
+            pass
+        return {"error": "timeout", "budget_s": args.c_layer_budget, "n_gpus": ngpus}
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": "child exited with %s: %s" % (p.returncode, (err or out).strip().splitlines()[-1:] or "")}
+    res = json.loads(lines[-1])
+    res["ran_in"] = "a child process of rank 0, before any rank touched a GPU (%.1f s of a %.0f s budget)" % (time.perf_counter() - t0,
+                                                                                                             args.c_layer_budget)
+    log(rank, "C layer on %d GPUs (child process): %s" % (ngpus, json.dumps({k: res[k] for k in res if k.startswith("chunks_")})))
+    return res
+
+
 def roofline_of(res, workload=None):
     achieved = res["alg_bytes_local"] / (res["kernel_ms"] * 1e-3) * 1e-9
     r = {"bound": "hbm", "kernel": res["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
          "alg_bytes_per_launch": res["alg_bytes_local"] / res.get("launches", 1),
          "ms_per_launch": round(res["kernel_ms"] / res.get("launches", 1), 5), "launches_per_product": res.get("launches", 1),
-         "ms_per_product": round(res["kernel_ms"], 5),
+         "ms_per_product": round(res["kernel_ms"], 5), "plan": res.get("plan"),
          "note": "HIP events on the launch stream over the timed products; one launch per product except the column "
                  "sweep's generations" +
                  ("; this kernel reads the plan's 16-bit column offsets (2 B per entry) where the algorithmic count has "
@@ -691,6 +852,22 @@ def main():
             raise SystemExit("--gpus %d needs one process per GPU: launch with torch.distributed.run" % args.gpus)
         args.gpus = world
 
+    if args.c_layer_child:      # child of rank 0 (N > 1): nothing but the C layer, its result as one JSON line
+        import smvp_toolkit_amd as sm
+        print(json.dumps(measure_c_layer(sm, args.rows, args.c_layer_child, max(5, args.steps), 0)), flush=True)
+        return
+    # N > 1: the C-layer leg first, in a child of rank 0, while no rank holds a GPU context; the others wait on a file
+    c_layer = None
+    if world > 1 and not args.no_c_layer and not args.no_config4 and not args.pmc_child:
+        import tempfile
+        flag = os.path.join(tempfile.gettempdir(), "smvp_bench_c_layer_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+        if rank == 0:
+            c_layer = c_layer_in_child(args, world, max(5, args.steps // 10), rank)
+            open(flag, "w").write("done\n")
+        else:
+            deadline = time.time() + args.c_layer_budget + 60.0
+            while not os.path.exists(flag) and time.time() < deadline:
+                time.sleep(0.2)
     if args.pmc_child:      # inner run of a counter pass: the headline product only
         args.no_tjds = args.no_random_model = args.no_samples = args.no_cpu_baseline = True
         args.no_config4 = args.no_pwt_tiled = args.no_live_traffic = True
@@ -731,7 +908,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    park = dist.new_group(backend="gloo") if (dist.is_initialized() and world > 1) else None   # CPU barrier for the C-layer leg
     dev_name, cus, hbm = sm.device_info(local_rank)
 
     # ------------------------------------------------------------ headline: CSR on the workload
@@ -762,8 +938,11 @@ def main():
             del coo
             tj = sm.tjds_from_coo_device(d_coo, blk["rows"], blk["cols_total"], blk["nnz"])   # radix sort + scans on the GPU
             del d_coo
+            torch.cuda.synchronize()
+            t_conv = time.perf_counter() - t0
             T = sm.TjdsMatrix(tj, device=local_rank)
             tname, tbytes = T.describe()
+            tpi = T.plan_info()
             log(rank, "TJDS built in %.1f s: %d jagged diagonals" % (time.perf_counter() - t0, tj.num_diag))
             stream = torch.cuda.current_stream()
             d_yt = torch.empty(blk["rows"], dtype=torch.float64, device="cuda")
@@ -790,6 +969,10 @@ def main():
                              "achieved_GBps": round(tbytes / (t_ms * 1e-3) * 1e-9, 1),
                              "frac_of_hbm_peak": round(tbytes / (t_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4),
                              "max_normwise_diff_vs_csr": terr, "steps": tsteps,
+                             "plan": {"plan_bytes": tpi["plan_bytes"], "matrix_bytes": tpi["matrix_bytes"],
+                                      "plan_over_matrix": round(tpi["plan_bytes"] / max(1.0, tpi["matrix_bytes"]), 3),
+                                      "plan_build_ms": round(tpi["build_ms"], 1)},
+                             "convert_device_ms": round(t_conv * 1e3, 1),
                              "traffic_bytes_per_product": trec[0] if trec else None,
                              "traffic_source": ("profiles/" + trec[1]) if trec else None,
                              "note": "ONE kernel per product: the entries regrouped by row at create time (val / row_ind / "
@@ -913,6 +1096,39 @@ def main():
         extra["sample_matrices"] = samples
 
     headline_roofline = roofline_of(res, blk["name"] + ", %s, x=%s" % (args.format.upper(), args.x))
+    # set-up beside the product (the reference's user waits for main-cli.c:340-365 / :766-926, not for the timed loop):
+    # COO -> CSR of the headline matrix on the GPU, and the host converter (one thread) on a slice of it
+    if rank == 0 and world == 1 and args.format == "csr" and not args.pmc_child:
+        try:
+            coo = np.zeros(blk["nnz"], dtype=sm.COO_DTYPE)
+            coo["row"] = np.repeat(np.arange(blk["rows"], dtype=np.int32), np.diff(blk["row_ptr"]))
+            coo["col"], coo["val"] = blk["col_ind"], blk["val"]
+            d_coo = torch.from_numpy(coo.view(np.uint8)).cuda()
+            torch.cuda.synchronize()
+            best = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                rp_d, ci_d, v_d = sm.csr_from_coo_device(d_coo, blk["rows"], blk["cols_total"], blk["nnz"])
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) * 1e3
+                best = dt if best is None else min(best, dt)
+            same = bool(torch.equal(rp_d.cpu(), torch.from_numpy(blk["row_ptr"])) and torch.equal(ci_d.cpu(), torch.from_numpy(blk["col_ind"])))
+            del d_coo, rp_d, ci_d, v_d
+            k = min(blk["rows"], 1 << 20)          # the first 2^20 rows on the host
+            nk = int(blk["row_ptr"][k])
+            t0 = time.perf_counter()
+            sm.csr_from_coo(coo[:nk], k)
+            host_ms = (time.perf_counter() - t0) * 1e3
+            del coo
+            headline_roofline["setup"] = {
+                "convert_device_ms": round(best, 1), "device_arrays_equal_input": same,
+                "convert_host_ms_sample": round(host_ms, 1), "host_sample": "%d rows, %d entries, one thread" % (k, nk),
+                "convert_host_ms_scaled_to_full": round(host_ms * blk["nnz"] / max(nk, 1), 1),
+                "note": "COO -> CSR (main-cli.c:340-365) of the headline matrix: smvp_csr_from_coo_device (radix sort + scan on the "
+                        "GPU, COO already in HBM) against smvp_csr_from_coo on the host; plan = the launch plan the product keeps "
+                        "beside the format's arrays (roofline.plan)"}
+        except Exception as e:
+            headline_roofline["setup"] = {"error": str(e)}
     if live:
         headline_roofline["traffic"], headline_roofline["traffic_source"] = live[0] / res.get("launches", 1), live[1]
     res["A"].close()
@@ -993,18 +1209,20 @@ def main():
         except Exception as e:
             extra["survey_random_model"] = {"error": str(e)}
 
-    # ------------------------------------------------------------ the C ABI's own sharded product on all GPUs (rank 0)
-    c_layer = None
-    if not args.no_c_layer and not args.no_config4 and not args.pmc_child:
+    # ------------------------------------------------------------ the C ABI's own sharded product (N = 1: here; N > 1: it ran
+    # first, in a child process of rank 0 -- see above)
+    if world == 1 and not args.no_c_layer and not args.no_config4 and not args.pmc_child:
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
-        if rank == 0:
-            try:
-                c_layer = measure_c_layer(sm, args.rows, world, max(5, args.steps // 10), rank)
-            except BaseException as e:   # a wrong result included: the other ranks are waiting on the barrier below,
-                c_layer = {"error": str(e) or type(e).__name__}    # so this leg reports its failure instead of ending the run
-        if park is not None:
-            dist.barrier(group=park)     # the other ranks wait here, on the CPU, with their GPUs idle
+        try:
+            c_layer = measure_c_layer(sm, args.rows, world, max(5, args.steps // 10), rank)
+        except BaseException as e:   # a wrong result included: this leg reports its failure instead of ending the run
+            c_layer = {"error": str(e) or type(e).__name__}
+    if rank == 0 and world > 1:
+        try:
+            os.remove(flag)
+        except Exception:
+            pass
 
     # ------------------------------------------------------------ roofline.others: every other kernel the line reports,
     # priced like the headline (algorithmic bytes of SURVEY 8(d) per product / measured time; traffic from this run's
@@ -1022,7 +1240,8 @@ def main():
     others = {}
     t = extra.get("tjds")
     if t and "error" not in t:
-        others["tjds"] = other(t["kernel"], t["ms_per_step"], t["alg_bytes_per_product"], blk["nnz"], "tjds", workload=blk["name"] + ", TJDS")
+        others["tjds"] = other(t["kernel"], t["ms_per_step"], t["alg_bytes_per_product"], blk["nnz"], "tjds", workload=blk["name"] + ", TJDS",
+                               plan=t.get("plan"), convert_device_ms=t.get("convert_device_ms"))
         if others["tjds"]["traffic"] is None and t.get("traffic_bytes_per_product"):
             others["tjds"]["traffic"], others["tjds"]["traffic_source"] = t["traffic_bytes_per_product"], t["traffic_source"]
     c4 = extra.get("config4")
@@ -1037,8 +1256,13 @@ def main():
                                                     "step_ms_products_then_allgather", "step_ms_overlapped",
                                                     "step_GFLOPs_products_then_allgather", "step_GFLOPs_overlapped",
                                                     "tile_kernel_spmv_only_ms", "exchange") if k in c4}
-            others["config4"]["note"] = ("the matrix BASELINE.md writes the >= 3.5x at 8 GPUs target on; its N = 1 point is "
-                                         "roofline.others.config4 of the N = 1 line (spmv_only_ms there)")
+            others["config4"]["note"] = ("the matrix BASELINE.md writes the >= 3.5x at 8 GPUs target on; t1_ms is the whole matrix on "
+                                         "one GPU of this node, measured in this run")
+        # the same keys at every N (N = 1: the step is the product, the speed-ups are 1)
+        for k in ("t1_ms", "tN_step_ms", "tN_step_after_ms", "tN_products_only_ms", "speedup_overlapped", "speedup_after",
+                  "speedup_products_only", "chunks_chosen", "chunk_choice", "plan", "eighth_of_n8", "chunks_chosen_for_n8"):
+            if k in c4:
+                others["config4"][k] = c4[k]
     if c_layer:
         others["config4_c_layer"] = c_layer
     if world > 1:   # the headline step's own product time (no exchange), so that the curve can be read both ways
@@ -1049,11 +1273,12 @@ def main():
                                                     "so the headline step is exchange-bound at N > 1 by construction"}
     pt = extra.get("pwt_tiled")
     if pt and "error" not in pt:
-        others["pwt_tiled_csr"] = other(pt["kernel"], pt["ms_per_launch"], pt["alg_bytes_per_product"], pt["nnz"], workload=pt["workload"])
+        others["pwt_tiled_csr"] = other(pt["kernel"], pt["ms_per_launch"], pt["alg_bytes_per_product"], pt["nnz"], workload=pt["workload"],
+                                        plan=pt.get("plan"))
         tj = pt.get("tjds")
         if tj:
             others["pwt_tiled_tjds"] = other(tj["kernel"], tj["ms_per_step"], tj["alg_bytes_per_product"], pt["nnz"],
-                                             workload=pt["workload"] + ", TJDS")
+                                             workload=pt["workload"] + ", TJDS", plan=tj.get("plan"))
     rm = extra.get("survey_random_model")
     if rm and "error" not in rm:
         others["survey_random_model"] = other(rm["kernel"], rm["ms_per_product"], rm["alg_bytes_per_product"], rm["nnz"],

@@ -283,12 +283,22 @@ void smvp_tjds_destroy(smvp_tjds_t *h);
  * (smvp_partition_rows); GPU g holds block g -- cut again into `chunks` row chunks, each its own CSR / TJDS handle --
  * plus all of x and produces its slice of y; RCCL ncclAllGather over xGMI puts the full y on every GPU, chunk c
  * travelling while chunk c+1 is multiplied.  devices NULL = 0 .. ngpus-1.  librccl is dlopen'ed on first use.
- * (bench.py does the same with one process per GPU.)  Verified on hardware with ONE GPU only so far (no multi-GPU
- * box is available to this project's tests); the N > 1 logic is covered by the gloo tests of the Python layer. */
+ * (bench.py does the same with one process per GPU.)  No multi-GPU box is available to this project's tests: on
+ * hardware the RCCL path has run with ONE GPU only; the N > 1 logic of this layer runs in the test suite through
+ * SMVP_EXCHANGE_COPIES with 2 ... 8 virtual ranks on one GPU, the Python layer's through gloo.
+ * When a rank fails inside a product its peers' collectives may never complete: smvp_sharded_spmv reports the error and
+ * marks the handle unusable (later calls fail at once, smvp_sharded_destroy aborts the communicators instead of waiting). */
 typedef struct smvp_sharded smvp_sharded_t;
+/* How the y blocks travel.  RCCL (default): ncclAllGather over xGMI, one communicator rank per GPU.  COPIES: every
+ * rank's thread pushes its chunks into every rank's buffer by device-to-device copies, the ranks ordered by events and
+ * a host-side meeting point -- no RCCL, and the device list may name one device several times ("virtual ranks"):
+ * the whole N-GPU code path (issuing threads, padded chunks, placement of the gathered pieces, both exchange forms,
+ * power iteration) then runs on fewer GPUs than ranks.  A rehearsal and test backend, not the fast path. */
+enum { SMVP_EXCHANGE_RCCL = 0, SMVP_EXCHANGE_COPIES = 1 };
 typedef struct smvp_shard_opts {
-    int chunks;  /* row chunks per GPU (the granularity of the product / all-gather overlap); 0 = 4 when ngpus > 1, else 1 */
-    int balance; /* 1 (default): blocks and chunks balanced by entries; 0: equal heights */
+    int chunks;   /* row chunks per GPU (the granularity of the product / all-gather overlap); 0 = 4 when ngpus > 1, else 1 */
+    int balance;  /* 1 (default): blocks and chunks balanced by entries; 0: equal heights */
+    int exchange; /* SMVP_EXCHANGE_*; with COPIES ngpus may exceed the visible devices (devices NULL = g % visible) */
 } smvp_shard_opts_t;
 void smvp_shard_opts_default(smvp_shard_opts_t *o);
 int smvp_csr_sharded_create(smvp_sharded_t **out, int ngpus, const int *devices, int rows, int cols, int nnz,
@@ -329,6 +339,7 @@ typedef struct smvp_run_opts {
     int normalize;      /* with iterate: divide every iterate by its largest magnitude (keeps 1000 steps finite) */
     int tjds_mode;      /* SMVP_TJDS_MODE_* for smvp_tjds_compute (AUTO = ROW_GATHER) */
     int timing;         /* SMVP_TIMING_*: how each product is timed */
+    int shard_exchange; /* ngpus > 1: SMVP_EXCHANGE_* (COPIES: ngpus may exceed the visible GPUs -- virtual ranks) */
     const double *x;    /* host operand, NULL = all ones (main-cli.c:368-369) */
 } smvp_run_opts_t;
 void smvp_run_opts_default(smvp_run_opts_t *o);

@@ -45,13 +45,13 @@
 
 enum { ALG_NONE = 0, ALG_CSR = 1 << 1, ALG_TJDS = 1 << 2, ALG_CISR = 1 << 3, ALG_ALL = 256 };
 enum { OPT_DEVICE = 1000, OPT_QUIRKS, OPT_KERNEL, OPT_USAGE, OPT_DEVCONV, OPT_GPUS, OPT_ITERATE, OPT_NORMALIZE, OPT_TIMING,
-       OPT_TJDS_MODE, OPT_EXPAND, OPT_CACHE, OPT_X, OPT_DUMP };
+       OPT_TJDS_MODE, OPT_EXPAND, OPT_CACHE, OPT_X, OPT_DUMP, OPT_VIRTUAL };
 
 static void usage(FILE *to, const char *prog)
 {
     fprintf(to,
             "Usage: %s [-acgt?] [-a|--all-algs] [-c|--csr] [-g|--cisr-gen] [-t|--tjds]\n"
-            "        [-n|--number=1000] [-s|--slots=16] [-d|--dir=./] [--device=0] [--gpus=1]\n"
+            "        [-n|--number=1000] [-s|--slots=16] [-d|--dir=./] [--device=0] [--gpus=1] [--virtual-gpus]\n"
             "        [--ref-quirks] [--iterate] [--normalize] [--device-convert] [--csr-kernel=auto|vector|stream|stream-carry|colsweep|binned]\n"
             "        [--tjds-mode=auto|row-gather|two-phase|atomic] [--timing=auto|events|device]\n"
             "        [--expand-symmetric] [--cache] [--x=ones|random] [--dump-arrays]\n"
@@ -73,6 +73,8 @@ static void help(const char *prog)
     puts("      --device=0           HIP device ordinal.");
     puts("      --gpus=1             Shard the matrix by row blocks over this many GPUs (RCCL all-gather of y;");
     puts("                           so far verified on hardware with one GPU only).");
+    puts("      --virtual-gpus       --gpus N with the y blocks exchanged by device-to-device copies instead of RCCL:");
+    puts("                           N may exceed the GPUs present (the ranks share them) -- a rehearsal of the N-GPU path.");
     puts("      --iterate            Power iteration: feed each result back as the next operand (x <- A x, n times).");
     puts("      --normalize          --iterate, and divide every iterate by its largest magnitude.");
     puts("      --ref-quirks         Reproduce the reference v0.6.4 TJDS output, defects included.");
@@ -280,11 +282,13 @@ int main(int argc, char *argv[])
         {"timing", required_argument, NULL, OPT_TIMING}, {"tjds-mode", required_argument, NULL, OPT_TJDS_MODE},
         {"expand-symmetric", no_argument, NULL, OPT_EXPAND}, {"cache", no_argument, NULL, OPT_CACHE},
         {"x", required_argument, NULL, OPT_X}, {"dump-arrays", no_argument, NULL, OPT_DUMP},
+        {"virtual-gpus", no_argument, NULL, OPT_VIRTUAL},
         {NULL, 0, NULL, 0}};
     const char *prog = "smvp-toolkit-cli";
     int alg_mode = ALG_NONE, calc_iter = 1000, cisr_slots = 16, device = 0, quirks = 0;
     int csr_kernel = SMVP_CSR_KERNEL_AUTO, device_convert = 0, ngpus = 1, iterate = 0, normalize = 0;
     int timing = SMVP_TIMING_AUTO, tjds_mode = SMVP_TJDS_MODE_AUTO, expand = 0, use_cache = 0, x_random = 0, dump = 0;
+    int virtual_gpus = 0;
     const char *report_dir = "";
 
     if (argc < 2) { /* main-cli.c:1267-1271 */
@@ -354,6 +358,9 @@ int main(int argc, char *argv[])
             if (parse_int(optarg, &v) != 0 || v < 1)
                 die("Invalid number of GPUs specified.");
             ngpus = v;
+            break;
+        case OPT_VIRTUAL:
+            virtual_gpus = 1;
             break;
         case OPT_KERNEL:
             if (strcmp(optarg, "auto") == 0)
@@ -561,7 +568,8 @@ int main(int argc, char *argv[])
         printf(CYAN "[DATA]\tCompute device %d: " RESET "%s, %d CUs, %.0f GiB\n", device, name, cus,
                (double)mem / (1024.0 * 1024.0 * 1024.0));
         if (ngpus > 1)
-            printf(CYAN "[DATA]\tRow blocks on %d GPUs, " RESET "RCCL all-gather of the result vector after each product\n", ngpus);
+            printf(CYAN "[DATA]\tRow blocks on %d %sGPUs, " RESET "%s of the result vector after each product\n", ngpus,
+                   virtual_gpus ? "virtual " : "", virtual_gpus ? "exchange by device-to-device copies" : "RCCL all-gather");
     }
 
     smvp_run_opts_t opts;
@@ -575,6 +583,7 @@ int main(int argc, char *argv[])
     opts.normalize = normalize;
     opts.timing = timing;
     opts.tjds_mode = tjds_mode;
+    opts.shard_exchange = virtual_gpus ? SMVP_EXCHANGE_COPIES : SMVP_EXCHANGE_RCCL;
     opts.x = x_operand;
     smvp_time_stats_t st;
     char path[4096];

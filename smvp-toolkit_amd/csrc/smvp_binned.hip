@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBinThreads) void csr_binned_far_products(
     for (int i = t; i < ncell && i < kBinShiftCap; i += kBinThreads)
         shift[i] = a_shift[sp + i];
     __syncthreads();
-    const int lane = t & 63, wave = t >> 6;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);  // (uniform: the chunk counts become scalar loads)
     const unsigned long long le = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1);
     for (int base = pa + wave * 256 * G; base < pz; base += (kBinThreads / 64) * 256 * G) {
         double2v v[2 * G];
@@ -177,9 +177,8 @@ __device__ unsigned long long g_binned_phase[8];
 template <int SLOTS, int THREADS, int G>
 __global__ __launch_bounds__(THREADS) void csr_binned_far_sums(
     const double *__restrict__ bins, const unsigned short *__restrict__ b_word, const int *__restrict__ b_chunk,
-    const int *__restrict__ b_ptr, const int *__restrict__ b_shift_ptr, const int *__restrict__ b_shift,
-    const int *__restrict__ blk_fr, const int *__restrict__ fr_row, const int *__restrict__ fr_ptr, double *__restrict__ y,
-    int nrb, int q)
+    const int4 *__restrict__ b_desc, const int *__restrict__ b_shift, const int *__restrict__ fr_row,
+    const int *__restrict__ fr_ptr, double *__restrict__ y, int nrb, int q)
 {
     extern __shared__ double lds[];  // all of it dynamic: the products' slots come first, 8-byte aligned
 #ifdef SMVP_PHASE_STAMPS
@@ -199,13 +198,15 @@ __global__ __launch_bounds__(THREADS) void csr_binned_far_sums(
     if (rb >= nrb)
         return;
     const int t = threadIdx.x;
-    const int a = b_ptr[rb], z = b_ptr[rb + 1];  // multiples of 256
+    // the block's descriptor, one scalar load (the first build chained b_ptr, blk_fr, fr_ptr[blk_fr]: two round trips)
+    const int4 d0 = b_desc[2 * rb], d1 = b_desc[2 * rb + 1];
+    const int a = d0.x, z = d0.y;  // its stretch of the stream: multiples of 256
     if (a >= z)
         return;  // (a row block without entries has no far rows either)
-    const int k0 = blk_fr[rb], k1 = blk_fr[rb + 1];
-    const int f0 = fr_ptr[k0];  // the row block's first far entry: slots count from it
-    const int sp = b_shift_ptr[rb], nruns = b_shift_ptr[rb + 1] - sp;
-    const int lane = t & 63, wave = t >> 6;
+    const int k0 = d0.z, k1 = d0.w;    // its far rows
+    const int f0 = d1.x;               // its first far entry: slots count from it
+    const int sp = d1.y, nruns = d1.z; // its sub-runs' shifts
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);  // (uniform: the chunk counts become scalar loads)
     const unsigned long long le = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1);
     // Everything that hangs on the scalars above goes out together, ahead of the one barrier the shifts need: the sub-runs'
     // shifts, this wavefront's first words and chunk counts, the bounds of this lane's first far rows.  (The first build
@@ -568,6 +569,19 @@ __global__ __launch_bounds__(256) void bin_emit(const u64 *__restrict__ key, con
     }
 }
 
+// b_desc[2 * rb] = {a, z, k0, k1}, b_desc[2 * rb + 1] = {f0, sp, nruns, 0}: what a workgroup of pass B reads first
+__global__ __launch_bounds__(256) void bin_block_desc(const int *__restrict__ b_ptr, const int *__restrict__ b_shift_ptr,
+                                                      const int *__restrict__ blk_fr, const int *__restrict__ fr_ptr, int nrb,
+                                                      int4 *__restrict__ desc)
+{
+    const int rb = blockIdx.x * 256 + threadIdx.x;
+    if (rb >= nrb)
+        return;
+    const int k0 = blk_fr[rb], k1 = blk_fr[rb + 1], sp = b_shift_ptr[rb];
+    desc[2 * rb] = make_int4(b_ptr[rb], b_ptr[rb + 1], k0, k1);
+    desc[2 * rb + 1] = make_int4(fr_ptr[k0], sp, b_shift_ptr[rb + 1] - sp, 0);
+}
+
 int scan_exclusive(const int *in, int *out, size_t n, Scratch &sc, hipStream_t st)
 {
     size_t bytes = 0;
@@ -665,7 +679,7 @@ void free_binned_plan(BinnedPlan *p)
     if (!p)
         return;
     for (void *q : {(void *)p->near_ptr, (void *)p->near_col, (void *)p->near_val, (void *)p->a_val, (void *)p->bins, (void *)p->fr_row,
-                    (void *)p->fr_ptr, (void *)p->blk_fr})
+                    (void *)p->fr_ptr, (void *)p->blk_fr, (void *)p->b_desc})
         if (q)
             (void)hipFree(q);
     free_stream(&p->a);
@@ -816,6 +830,10 @@ int build_binned_plan(const int *d_row_ptr, const int *d_col_ind, const double *
         return rc;
     if (int rc = build_stream(k1, i1, nf, (u64)P.ncb, P.nrb, binpos, false, nullptr, nullptr, P.blk_fr, P.fr_ptr, &P.b, nullptr, &P.plan_bytes, st))
         return rc;
+    if (int rc = own(&P.b_desc, (size_t)P.nrb * 2 + 2, &P.plan_bytes))
+        return rc;
+    hipLaunchKernelGGL(bin_block_desc, dim3(blocks_for(P.nrb)), dim3(256), 0, st, P.b.ptr, P.b.shift_ptr, P.blk_fr, P.fr_ptr, P.nrb, P.b_desc);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     return SMVP_OK;
 }
@@ -832,6 +850,7 @@ static hipError_t ask_for_lds()
         e = hipFuncSetAttribute((const void *)csr_binned_far_products<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsA);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)csr_binned_far_sums<8192, 1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b_bytes(8192));
+
         if (e != hipSuccess)
             return e;
         asked.fetch_or(1ull << dev);
@@ -864,7 +883,7 @@ hipError_t launch_binned_sums(const BinnedPlan &p, double *y, hipStream_t stream
 #define SMVP_BINNED_B(S, T, GG)                                                                                                  \
     if (p.slots == S && p.threads_b == T) {                                                                                    \
         hipLaunchKernelGGL((csr_binned_far_sums<S, T, GG>), dim3(grid_b), dim3(T), lds_b_bytes(S), stream, p.bins, p.b.word, p.b.chunk, \
-                           p.b.ptr, p.b.shift_ptr, p.b.shift, p.blk_fr, p.fr_row, p.fr_ptr, y, p.nrb, p.q);                     \
+                           p.b_desc, p.b.shift, p.fr_row, p.fr_ptr, y, p.nrb, p.q);                                              \
         return hipGetLastError();                                                                                              \
     }
     SMVP_BINNED_B(8192, 1024, 2)

@@ -1584,15 +1584,18 @@ static int sharded_compute(bool tjds, const smvp_coo_t *coo, int rows, int cols,
     if (o->timing == SMVP_TIMING_DEVICE)  // the in-kernel stamps time one launch of one GPU; a sharded product is several
         return smvp::fail(SMVP_ERR_UNSUPPORTED, "device-side timing is not available with more than one GPU (use events)");
     smvp_sharded_t *h = nullptr;
+    smvp_shard_opts_t so;
+    smvp_shard_opts_default(&so);
+    so.exchange = o->shard_exchange;
     int rc;
     if (tjds) {
-        rc = smvp_tjds_sharded_create(&h, o->ngpus, nullptr, coo, rows, cols, nnz);
+        rc = smvp_tjds_sharded_create_ex(&h, o->ngpus, nullptr, coo, rows, cols, nnz, &so);
     } else {
         std::vector<int> row_ptr((size_t)rows + 1), col_ind((size_t)std::max(nnz, 1));
         std::vector<double> val((size_t)std::max(nnz, 1));
         rc = smvp_csr_from_coo(coo, rows, nnz, row_ptr.data(), col_ind.data(), val.data());
         if (rc == SMVP_OK)
-            rc = smvp_csr_sharded_create(&h, o->ngpus, nullptr, rows, cols, nnz, row_ptr.data(), col_ind.data(), val.data());
+            rc = smvp_csr_sharded_create_ex(&h, o->ngpus, nullptr, rows, cols, nnz, row_ptr.data(), col_ind.data(), val.data(), &so);
     }
     std::vector<double> local;
     if (!time_each_ms) {

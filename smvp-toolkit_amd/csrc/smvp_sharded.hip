@@ -17,6 +17,12 @@
 //
 // librccl is loaded with dlopen the first time a sharded handle is created, so
 // single-GPU runs neither link nor load it.
+//
+// opts.exchange = SMVP_EXCHANGE_COPIES replaces the RCCL calls by peer copies: every rank's thread pushes its chunk into
+// every rank's wire buffer (hipMemcpyAsync, device to device) and the ranks order themselves with events and a host
+// barrier.  It accepts any device list -- also ONE device several times -- so that the N-GPU code (issuing threads,
+// padded chunks, placement of the gathered pieces across ranks, both exchange forms, power iteration, early destroy)
+// runs on a one-GPU box: "virtual ranks".  It is a rehearsal and test backend, not the fast path over xGMI.
 #include "smvp_common.h"
 #include "smvp_kernels.h"
 
@@ -47,6 +53,7 @@ struct Rccl {
     void *lib = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -82,6 +89,7 @@ int load_rccl(Rccl **out)
         r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
         r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        r.CommAbort = (decltype(r.CommAbort))dlsym(r.lib, "ncclCommAbort");
         if (missing)
             r.why = std::string("missing symbol ") + missing;
         else
@@ -145,6 +153,18 @@ struct smvp_sharded {
     std::vector<ncclComm_t> comm;
     std::vector<unsigned long long *> d_norm;
     Rccl *rccl = nullptr;
+    // exchange by copies (virtual ranks): ev_pushed[g] = rank g's pieces of this product have landed everywhere,
+    // ev_placed[g] = rank g has read its wire buffer (it may be written again); `phase` lines the issuing threads up
+    // between recording those events and waiting for them
+    int exchange = SMVP_EXCHANGE_RCCL;
+    std::vector<hipEvent_t> ev_pushed, ev_placed;
+    std::mutex phase_mu;
+    std::condition_variable phase_cv;
+    int phase_waiting = 0;
+    unsigned long long phase_round = 0;
+    bool phase_abort = false;  // a rank failed: nobody waits at the meeting point any more
+    bool broken = false;  // a rank failed inside a product: its peers' collectives may never complete
+    std::string broken_why;
 
     // n > 1: one issuing thread per GPU, woken for every product (issue_product)
     std::vector<std::thread> issuer;
@@ -181,8 +201,12 @@ extern "C" void smvp_sharded_destroy(smvp_sharded_t *h)
     for (int g = 0; g < (int)h->device.size(); ++g) {
         const size_t i = (size_t)g;
         (void)hipSetDevice(h->device[i]);
-        if (i < h->comm.size() && h->comm[i] && h->rccl)
-            h->rccl->CommDestroy(h->comm[i]);
+        if (i < h->comm.size() && h->comm[i] && h->rccl) {
+            if (h->broken && h->rccl->CommAbort)
+                h->rccl->CommAbort(h->comm[i]);  // a collective some rank never joined would not let CommDestroy return
+            else
+                h->rccl->CommDestroy(h->comm[i]);
+        }
         for (int c = 0; c < h->chunks; ++c) {
             const size_t k = i * (size_t)h->chunks + (size_t)c;
             if (k < h->csr.size())
@@ -199,7 +223,7 @@ extern "C" void smvp_sharded_destroy(smvp_sharded_t *h)
             (void)hipFree(h->d_seg[i]);
         if (i < h->d_norm.size() && h->d_norm[i])
             (void)hipFree(h->d_norm[i]);
-        for (auto *vec : {&h->ev0, &h->ev1, &h->ev_gathered})
+        for (auto *vec : {&h->ev0, &h->ev1, &h->ev_gathered, &h->ev_pushed, &h->ev_placed})
             if (i < vec->size() && (*vec)[i])
                 (void)hipEventDestroy((*vec)[i]);
         for (auto *vec : {&h->stream, &h->comm_stream})
@@ -215,6 +239,7 @@ extern "C" void smvp_shard_opts_default(smvp_shard_opts_t *o)
         return;
     o->chunks = 0;
     o->balance = 1;
+    o->exchange = SMVP_EXCHANGE_RCCL;
 }
 
 namespace {
@@ -227,23 +252,27 @@ int sharded_common(smvp_sharded *h, int ngpus, const int *devices, int rows, int
     int visible = 0;
     if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0)
         return smvp::fail(SMVP_ERR_NO_DEVICE, "no HIP device is visible (this engine has no CPU path)");
-    if (ngpus < 1 || ngpus > visible)
-        return smvp::fail(SMVP_ERR_INVALID, "%d GPUs requested, %d visible", ngpus, visible);
     smvp_shard_opts_t def;
     smvp_shard_opts_default(&def);
     const smvp_shard_opts_t *o = opts ? opts : &def;
+    if (o->exchange != SMVP_EXCHANGE_RCCL && o->exchange != SMVP_EXCHANGE_COPIES)
+        return smvp::fail(SMVP_ERR_INVALID, "unknown exchange %d", o->exchange);
+    const bool copies = o->exchange == SMVP_EXCHANGE_COPIES;  // ranks may share a device ("virtual ranks")
+    if (ngpus < 1 || (!copies && ngpus > visible) || ngpus > 64)
+        return smvp::fail(SMVP_ERR_INVALID, "%d GPUs requested, %d visible", ngpus, visible);
     if (o->chunks < 0 || o->chunks > 64)
         return smvp::fail(SMVP_ERR_INVALID, "chunks per GPU must lie in [1, 64] (0 = default)");
+    h->exchange = o->exchange;
     h->n = ngpus;
     h->chunks = o->chunks > 0 ? o->chunks : (ngpus > 1 ? 4 : 1);
     h->rows = rows, h->cols = cols, h->nnz = nnz;
     const size_t n = (size_t)ngpus, C = (size_t)h->chunks;
     for (int g = 0; g < ngpus; ++g) {
-        const int dev = devices ? devices[g] : g;
+        const int dev = devices ? devices[g] : (copies ? g % visible : g);
         if (dev < 0 || dev >= visible)
             return smvp::fail(SMVP_ERR_INVALID, "device %d out of range", dev);
         for (int p : h->device)
-            if (p == dev)
+            if (p == dev && !copies)
                 return smvp::fail(SMVP_ERR_INVALID, "device %d listed twice", dev);
         h->device.push_back(dev);
     }
@@ -298,7 +327,7 @@ int sharded_common(smvp_sharded *h, int ngpus, const int *devices, int rows, int
     for (auto *vec : {&h->d_x, &h->d_y_local, &h->d_wire, &h->d_y_full})
         vec->assign(n, nullptr);
     h->d_seg.assign(n, nullptr);
-    for (auto *vec : {&h->ev0, &h->ev1, &h->ev_gathered})
+    for (auto *vec : {&h->ev0, &h->ev1, &h->ev_gathered, &h->ev_pushed, &h->ev_placed})
         vec->assign(n, nullptr);
     h->ev_chunk.assign(n * C, nullptr);
     h->d_norm.assign(n, nullptr);
@@ -310,6 +339,9 @@ int sharded_common(smvp_sharded *h, int ngpus, const int *devices, int rows, int
         for (auto *vec : {&h->ev0, &h->ev1})
             HIP_TRY(hipEventCreate(&(*vec)[g]));
         HIP_TRY(hipEventCreateWithFlags(&h->ev_gathered[g], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_pushed[g], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_placed[g], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(h->ev_placed[g], h->stream[g]));  // (nothing to wait for before the first product)
         for (size_t c = 0; c < C; ++c)
             HIP_TRY(hipEventCreateWithFlags(&h->ev_chunk[g * C + c], hipEventDisableTiming));
         HIP_TRY(hipMalloc((void **)&h->d_x[g], sizeof(double) * vec_len));
@@ -322,6 +354,20 @@ int sharded_common(smvp_sharded *h, int ngpus, const int *devices, int rows, int
         HIP_TRY(hipMemset(h->d_wire[g], 0, sizeof(double) * h->woff[C]));
         HIP_TRY(hipMemset(h->d_y_full[g], 0, sizeof(double) * vec_len));
         HIP_TRY(hipMemcpy(h->d_seg[g], seg.data(), sizeof(int4) * seg.size(), hipMemcpyHostToDevice));
+    }
+    if (copies) {
+        // pieces travel by device-to-device copies: let every device reach its peers' buffers where they differ
+        for (size_t g = 0; g < n; ++g)
+            for (size_t r = 0; r < n; ++r)
+                if (h->device[g] != h->device[r]) {
+                    HIP_TRY(hipSetDevice(h->device[g]));
+                    const hipError_t e = hipDeviceEnablePeerAccess(h->device[r], 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                        return smvp::fail(SMVP_ERR_HIP, "device %d cannot reach device %d: %s", h->device[g], h->device[r],
+                                          hipGetErrorString(e));
+                    (void)hipGetLastError();
+                }
+        return SMVP_OK;
     }
     if (int rc = load_rccl(&h->rccl))
         return rc;
@@ -495,6 +541,34 @@ namespace {
 // `timed` brackets all of it with an event pair; TJDS chunks that need a cleared y get it first, outside the pair
 // (main-cli.c:1008).  Runs on GPU g's issuing thread (the caller's own when there is one GPU): every communicator
 // rank is driven by one thread, the ranks' calls come in the same order, so no grouping is needed.
+// Host-side meeting of the issuing threads (exchange by copies): returns when all h->n of them have arrived.  A thread
+// whose product failed still comes here (issue_product_guarded), so nobody waits for ever.
+void phase_barrier(smvp_sharded *h)
+{
+    if (h->n <= 1)
+        return;
+    std::unique_lock<std::mutex> lock(h->phase_mu);
+    if (h->phase_abort)
+        return;
+    const unsigned long long round = h->phase_round;
+    if (++h->phase_waiting == h->n) {
+        h->phase_waiting = 0;
+        ++h->phase_round;
+        h->phase_cv.notify_all();
+    } else {
+        h->phase_cv.wait(lock, [&] { return h->phase_abort || h->phase_round != round; });
+    }
+}
+
+void phase_give_up(smvp_sharded *h)
+{
+    {
+        std::lock_guard<std::mutex> lock(h->phase_mu);
+        h->phase_abort = true;
+    }
+    h->phase_cv.notify_all();
+}
+
 int issue_product(smvp_sharded *h, size_t g, int allgather, int timed)
 {
     const size_t C = (size_t)h->chunks;
@@ -506,7 +580,15 @@ int issue_product(smvp_sharded *h, size_t g, int allgather, int timed)
                 return rc;
     if (timed)
         HIP_TRY(hipEventRecord(h->ev0[g], h->stream[g]));
+    const bool copies = h->exchange == SMVP_EXCHANGE_COPIES;
+    const size_t n = (size_t)h->n;
     auto gather = [&](size_t c, hipStream_t st) -> int {
+        if (copies) {  // this rank's piece of chunk c into every rank's wire buffer
+            for (size_t r = 0; r < n; ++r)
+                HIP_TRY(hipMemcpyAsync(h->d_wire[r] + h->woff[c] + g * (size_t)h->pad[c], h->d_y_local[g] + h->loff[c],
+                                       sizeof(double) * (size_t)h->pad[c], hipMemcpyDeviceToDevice, st));
+            return SMVP_OK;
+        }
         const ncclResult_t nr = h->rccl->AllGather(h->d_y_local[g] + h->loff[c], h->d_wire[g] + h->woff[c], (size_t)h->pad[c],
                                                    ncclDouble, h->comm[g], st);
         if (nr != ncclSuccess)
@@ -535,10 +617,22 @@ int issue_product(smvp_sharded *h, size_t g, int allgather, int timed)
             HIP_TRY(hipEventRecord(h->ev_gathered[g], h->comm_stream[g]));
             HIP_TRY(hipStreamWaitEvent(h->stream[g], h->ev_gathered[g], 0));
         }
+        if (copies) {
+            // every rank's pieces must have landed here before they are placed: each rank records "pushed" behind its
+            // own copies, the issuing threads meet (so that every event has been recorded), then each waits for all
+            HIP_TRY(hipEventRecord(h->ev_pushed[g], h->stream[g]));
+            phase_barrier(h);
+            for (size_t r = 0; r < n; ++r)
+                HIP_TRY(hipStreamWaitEvent(h->stream[g], h->ev_pushed[r], 0));
+        }
         if (h->rows > 0) {
             hipLaunchKernelGGL(place_gathered, dim3((unsigned)((h->rows + 255) / 256)), dim3(256), 0, h->stream[g], h->d_wire[g],
                                h->d_y_full[g], h->d_seg[g], h->nseg, h->rows);
             HIP_TRY(hipGetLastError());
+        }
+        if (copies) {
+            HIP_TRY(hipEventRecord(h->ev_placed[g], h->stream[g]));
+            phase_barrier(h);  // the next product's copies wait for these events: all recorded before anybody goes on
         }
     }
     if (timed)
@@ -560,6 +654,8 @@ void issuer_main(smvp_sharded *h, size_t g)
             allgather = h->job_allgather, timed = h->job_timed;
         }
         const int rc = issue_product(h, g, allgather, timed);
+        if (rc != SMVP_OK)
+            phase_give_up(h);  // (exchange by copies) the peers must not wait for this rank at the meeting points
         {
             std::lock_guard<std::mutex> lock(h->mu);
             h->job_rc[g] = rc;
@@ -577,6 +673,8 @@ extern "C" int smvp_sharded_spmv(smvp_sharded_t *h, int allgather, int timed)
 {
     if (!h || allgather < 0 || allgather > SMVP_GATHER_AFTER)
         return smvp::fail(SMVP_ERR_INVALID, "smvp_sharded_spmv: bad argument");
+    if (h->broken)
+        return smvp::fail(SMVP_ERR_HIP, "the sharded handle is unusable after a failed product (%s): destroy it", h->broken_why.c_str());
     const size_t n = (size_t)h->n;
     static const bool always_threads = [] {
         const char *e = getenv("SMVP_SHARDED_THREADS");  // development switch: the issuing threads with one GPU too
@@ -584,7 +682,12 @@ extern "C" int smvp_sharded_spmv(smvp_sharded_t *h, int allgather, int timed)
     }();
     if (n == 1 && !always_threads) {
         DeviceScope keep;
-        return issue_product(h, 0, allgather, timed);
+        const int rc = issue_product(h, 0, allgather, timed);
+        if (rc != SMVP_OK && allgather) {
+            h->broken = true;
+            h->broken_why = smvp_last_error();
+        }
+        return rc;
     }
     if (h->issuer.empty()) {
         h->job_rc.assign(n, SMVP_OK);
@@ -601,8 +704,14 @@ extern "C" int smvp_sharded_spmv(smvp_sharded_t *h, int allgather, int timed)
         h->cv_done.wait(lock, [&] { return h->pending == 0; });
     }
     for (size_t g = 0; g < n; ++g)
-        if (h->job_rc[g] != SMVP_OK)
+        if (h->job_rc[g] != SMVP_OK) {
+            // The other ranks have enqueued (or will never get) their side of this product's collectives: those may never
+            // complete.  The handle is marked broken so that the error surfaces here and synchronize / destroy do not wait
+            // on the device for them (destroy aborts the communicators).
+            h->broken = true;
+            h->broken_why = "GPU " + std::to_string(h->device[g]) + ": " + h->job_err[g];
             return smvp::fail(h->job_rc[g], "GPU %d: %s", h->device[g], h->job_err[g].c_str());
+        }
     return SMVP_OK;
 }
 
@@ -632,6 +741,8 @@ extern "C" int smvp_sharded_synchronize(smvp_sharded_t *h, double *ms)
 {
     if (!h)
         return smvp::fail(SMVP_ERR_INVALID, "null handle");
+    if (h->broken)
+        return smvp::fail(SMVP_ERR_HIP, "the sharded handle is unusable after a failed product (%s): destroy it", h->broken_why.c_str());
     DeviceScope keep;
     double worst = 0.0;
     for (size_t g = 0; g < (size_t)h->n; ++g) {

@@ -37,7 +37,7 @@ class RunOpts(C.Structure):
     _fields_ = [("device", C.c_int), ("csr_kernel", C.c_int), ("csr_param", C.c_int),
                 ("tjds_ref_quirks", C.c_int), ("convert_on_device", C.c_int), ("ngpus", C.c_int),
                 ("iterate", C.c_int), ("normalize", C.c_int), ("tjds_mode", C.c_int), ("timing", C.c_int),
-                ("x", C.c_void_p)]
+                ("shard_exchange", C.c_int), ("x", C.c_void_p)]
 
 
 class PlanInfo(C.Structure):
@@ -49,10 +49,11 @@ class RunInfo(C.Structure):
 
 
 class ShardOpts(C.Structure):
-    _fields_ = [("chunks", C.c_int), ("balance", C.c_int)]
+    _fields_ = [("chunks", C.c_int), ("balance", C.c_int), ("exchange", C.c_int)]
 
 
 GATHER_NONE, GATHER_OVERLAPPED, GATHER_AFTER = 0, 1, 2
+EXCHANGE_RCCL, EXCHANGE_COPIES = 0, 1
 
 
 class SmvpError(RuntimeError):
@@ -536,12 +537,12 @@ class TjdsMatrix:
 class ShardedMatrix:
     """Row blocks of one matrix on several GPUs of this process (smvp_sharded_t), RCCL all-gather of y."""
 
-    def __init__(self, fmt, ngpus, rows, cols, coo=None, csr=None, devices=None, chunks=0, balance=True):
+    def __init__(self, fmt, ngpus, rows, cols, coo=None, csr=None, devices=None, chunks=0, balance=True, exchange=EXCHANGE_RCCL):
         self._h = C.c_void_p()
         devs = None if devices is None else (C.c_int * ngpus)(*devices)
         o = ShardOpts()
         lib().smvp_shard_opts_default(C.byref(o))
-        o.chunks, o.balance = int(chunks), int(balance)
+        o.chunks, o.balance, o.exchange = int(chunks), int(balance), int(exchange)
         if fmt == "csr":
             rp, ci, v = csr
             nnz = int(rp[rows])
@@ -607,13 +608,13 @@ class ShardedMatrix:
 
 # ------------------------------------------------- reference-shaped entry points
 def _run_opts(device, csr_kernel, csr_param, ref_quirks, x, device_convert=False, ngpus=0, iterate=False,
-              normalize=False, tjds_mode=TJDS_MODE_AUTO, timing=TIMING_AUTO):
+              normalize=False, tjds_mode=TJDS_MODE_AUTO, timing=TIMING_AUTO, exchange=EXCHANGE_RCCL):
     o = RunOpts()
     lib().smvp_run_opts_default(C.byref(o))
     o.device, o.csr_kernel, o.csr_param, o.tjds_ref_quirks = device, csr_kernel, csr_param, int(ref_quirks)
     o.convert_on_device, o.ngpus = int(device_convert), int(ngpus)
     o.iterate, o.normalize = int(iterate), int(normalize)
-    o.tjds_mode, o.timing = int(tjds_mode), int(timing)
+    o.tjds_mode, o.timing, o.shard_exchange = int(tjds_mode), int(timing), int(exchange)
     keep = None
     if x is not None:
         keep = _arr(x, np.float64)
@@ -629,21 +630,21 @@ def last_run_info():
 
 
 def csr_compute(coo, rows, cols, iters=1, device=0, kernel=CSR_KERNEL_AUTO, param=0, x=None, device_convert=False,
-                ngpus=0, iterate=False, normalize=False, timing=TIMING_AUTO):
+                ngpus=0, iterate=False, normalize=False, timing=TIMING_AUTO, exchange=EXCHANGE_RCCL):
     """smvp_csr_compute: COO in, (y, per-iteration ms, TimeStats) out."""
     nnz = len(coo)
     coo = _arr(coo, COO_DTYPE)
     y = np.zeros(max(rows, 1), dtype=np.float64)
     ms = np.zeros(iters, dtype=np.float64)
     st = TimeStats()
-    o, keep = _run_opts(device, kernel, param, False, x, device_convert, ngpus, iterate, normalize, timing=timing)
+    o, keep = _run_opts(device, kernel, param, False, x, device_convert, ngpus, iterate, normalize, timing=timing, exchange=exchange)
     _check(lib().smvp_csr_compute(_p(coo), rows, cols, nnz, iters, C.byref(o), _p(y), _p(ms), C.byref(st)),
            "smvp_csr_compute")
     return y[:rows], ms, st
 
 
 def tjds_compute(coo, rows, cols, iters=1, device=0, ref_quirks=False, x=None, device_convert=False, ngpus=0,
-                 iterate=False, normalize=False, mode=TJDS_MODE_AUTO, timing=TIMING_AUTO):
+                 iterate=False, normalize=False, mode=TJDS_MODE_AUTO, timing=TIMING_AUTO, exchange=EXCHANGE_RCCL):
     """smvp_tjds_compute: COO in, (y, per-iteration ms, TimeStats) out."""
     nnz = len(coo)
     coo = _arr(coo, COO_DTYPE)
@@ -651,7 +652,7 @@ def tjds_compute(coo, rows, cols, iters=1, device=0, ref_quirks=False, x=None, d
     ms = np.zeros(iters, dtype=np.float64)
     st = TimeStats()
     o, keep = _run_opts(device, CSR_KERNEL_AUTO, 0, ref_quirks, x, device_convert, ngpus, iterate, normalize,
-                        tjds_mode=mode, timing=timing)
+                        tjds_mode=mode, timing=timing, exchange=exchange)
     _check(lib().smvp_tjds_compute(_p(coo), rows, cols, nnz, iters, C.byref(o), _p(y), _p(ms), C.byref(st)),
            "smvp_tjds_compute")
     return y[:rows], ms, st

@@ -130,3 +130,57 @@ class ChunkedExchange:
             if w is not None:
                 w.wait()
         return self.y_full[:self.rows_total]
+
+
+# ------------------------------------------------------------------ how many chunks per rank?
+XGMI_LINK_GBPS = 153.0   # one xGMI link, one direction; an MI355X has seven, one to every peer of an 8-GPU node
+
+
+def gather_ms_bounds(piece_bytes, world):
+    """(direct, ring) milliseconds for one all-gather in which every rank contributes `piece_bytes`: every GPU must
+    receive world - 1 pieces -- each over its own link at best (direct), all through one link at worst (a ring)."""
+    if world <= 1:
+        return 0.0, 0.0
+    direct = piece_bytes / (XGMI_LINK_GBPS * 1e9) * 1e3
+    return direct, direct * (world - 1)
+
+
+def overlapped_step_ms(product_ms_total, chunks, gather_ms_per_chunk):
+    """End of the last all-gather when chunk c's gather is issued right behind its product and the gathers run one
+    after the other on the communication stream (what ChunkedExchange.step(overlap=True) and the C layer do)."""
+    p = product_ms_total / chunks
+    t = 0.0
+    for c in range(chunks):
+        t = max(t, (c + 1) * p) + gather_ms_per_chunk
+    return t
+
+
+def choose_chunks(product_ms, y_bytes_per_rank, world, gather_ms=None):
+    """Chunks per rank for the overlapped product / all-gather step.
+
+    product_ms: {chunks: MEASURED ms of this rank's local products when its block is cut into that many chunks} -- the
+    column sweep pays for every chunk (each pulls all of x into the L2s again), so more chunks are not free;
+    y_bytes_per_rank: 8 * rows per rank, what the rank contributes per product; gather_ms: {chunks: measured ms of ONE
+    chunk's all-gather} where it could be measured (world > 1), else the two link models of gather_ms_bounds.
+    With a measurement the choice is the shortest estimated step; without, the candidate with the smallest worst-case
+    regret over the two link models.  Returns {"chosen", "estimates_ms": {chunks: {...}}, "inputs": {...}}.
+    """
+    cands = sorted(product_ms)
+    est = {}
+    for c in cands:
+        if gather_ms and c in gather_ms:
+            est[c] = {"measured_gather": overlapped_step_ms(product_ms[c], c, gather_ms[c])}
+        else:
+            d, r = gather_ms_bounds(y_bytes_per_rank / c, world)
+            est[c] = {"direct_links": overlapped_step_ms(product_ms[c], c, d), "one_link_ring": overlapped_step_ms(product_ms[c], c, r)}
+    models = sorted({m for e in est.values() for m in e})
+    best = {m: min(est[c][m] for c in cands if m in est[c]) for m in models}
+    regret = {c: max(est[c][m] - best[m] for m in models if m in est[c]) for c in cands}
+    chosen = min(cands, key=lambda c: (regret[c], c))
+    return {"chosen": chosen,
+            "estimates_ms": {c: {m: round(v, 4) for m, v in est[c].items()} for c in cands},
+            "inputs": {"product_ms_by_chunks": {c: round(product_ms[c], 4) for c in cands}, "y_bytes_per_rank": y_bytes_per_rank,
+                       "world": world, "link_GBps": XGMI_LINK_GBPS,
+                       "gather_ms_by_chunks": {c: round(v, 4) for c, v in gather_ms.items()} if gather_ms else None},
+            "rule": "shortest estimated overlapped step" if gather_ms else
+                    "smallest worst-case regret over the direct-links and one-link-ring models of the all-gather"}

@@ -363,6 +363,41 @@ def test_csr_matrix_without_rows(torch, kernel, param):
     A.close()
 
 
+def test_plan_info_bounds(torch):
+    """smvp_csr_plan_info / smvp_tjds_plan_info: what each launch plan keeps beside the format's own arrays.  The tile plan
+    of CSR is a few words per tile (+ 2 B per entry where the 16-bit column offsets engage): never more than half the
+    matrix again; the column sweep and the binned plan keep the entries a second time (about 14 / 12.6 = 1.1 and up to
+    20 / 12 = 1.7 times the matrix); the one-kernel TJDS plan 6.2 B of index per entry plus the cached values."""
+    m, n, coo = load("memplus.mtx")
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    A = sm.CsrMatrix(m, n, row_ptr, col_ind, val)
+    i = A.plan_info()
+    assert i["matrix_bytes"] == 12.0 * len(val) + 4.0 * (m + 1) and 0 < i["plan_bytes"] <= 0.5 * i["matrix_bytes"] and i["build_ms"] > 0
+    A.set_kernel(sm.CSR_KERNEL_VECTOR, 8)
+    assert A.plan_info()["plan_bytes"] == 0
+    A.set_kernel(sm.CSR_KERNEL_COLSWEEP, 0)
+    assert 1.0 * i["matrix_bytes"] < A.plan_info()["plan_bytes"] < 1.25 * i["matrix_bytes"]
+    A.set_kernel(sm.CSR_KERNEL_BINNED, 64)
+    assert 0.9 * i["matrix_bytes"] < A.plan_info()["plan_bytes"] < 2.2 * i["matrix_bytes"]
+    A.close()
+    T = sm.TjdsMatrix(sm.tjds_from_coo(coo, m, n))
+    t = T.plan_info()
+    assert t["matrix_bytes"] == 12.0 * len(val) + 4.0 * (T.t.num_diag + 1) + 4.0 * n if hasattr(T, "t") else t["matrix_bytes"] > 12.0 * len(val)
+    assert 0.5 * t["matrix_bytes"] < t["plan_bytes"] < 1.6 * t["matrix_bytes"] and t["build_ms"] > 0
+    T.set_mode(sm.TJDS_MODE_TWO_PHASE)
+    assert T.plan_info()["plan_bytes"] > t["plan_bytes"] + 12.0 * len(val)       # + the products and the row-inverted index
+    T.close()
+    # a 16-bit-offset plan on a large banded matrix: tile words + 2 B per entry
+    nb = 2_000_000
+    band = ((np.arange(nb, dtype=np.int64)[:, None] + np.arange(-4, 4)) % nb).astype(np.int32)
+    band.sort(axis=1)
+    B = sm.CsrMatrix(nb, nb, (np.arange(nb + 1, dtype=np.int64) * 8).astype(np.int32), band.ravel(), np.ones(8 * nb))
+    b = B.plan_info()
+    assert B.describe()[0] == "csr_stream_owner<8, 5, false>" and 2.0 * 8 * nb < b["plan_bytes"] < 2.1 * 8 * nb
+    assert b["plan_bytes"] <= 1.5 * b["matrix_bytes"]
+    B.close()
+
+
 def test_auto_plan_choice(torch):
     """AUTO: owner-completes tiles by default, the carry form when some row is extremely long; never the vector kernel;
     the column sweep only for large matrices whose gathers scatter over an operand much larger than the L2."""
@@ -997,6 +1032,17 @@ def test_bench_script_runs_small(torch):
     cl = o["config4_c_layer"]
     assert cl["n_gpus"] == 1 and all(cl["chunks_%d" % c][f]["event_ms"] > 0 for c in (1, 4)
                                      for f in ("products_only", "products_then_allgather", "overlapped"))
+    # round 4: what the plans cost, the set-up beside the product, the speed-up keys (the same at every N), the chunk choice
+    assert j["roofline"]["plan"]["plan_bytes"] > 0 and j["roofline"]["plan"]["plan_build_ms"] > 0
+    assert j["roofline"]["setup"]["device_arrays_equal_input"] and j["roofline"]["setup"]["convert_device_ms"] > 0
+    for key in ("t1_ms", "tN_step_ms", "tN_step_after_ms", "speedup_overlapped", "speedup_after", "chunks_chosen", "plan"):
+        assert key in o["config4"], key
+    assert o["config4"]["speedup_overlapped"] == 1.0 and o["config4"]["chunks_chosen"] == 1
+    assert o["config4"]["chunks_chosen_for_n8"] in (1, 2, 4) and set(o["config4"]["eighth_of_n8"]["estimates_ms"]) == {"1", "2", "4"}
+    rm = o["survey_random_model"]
+    assert rm["bit_identical_run_to_run"] and rm["plan"]["plan_bytes"] >= 0 and rm["launches_per_product"] >= 1
+    assert "plan" in o["tjds"] and o["tjds"]["convert_device_ms"] > 0 and "plan" in o["pwt_tiled_csr"] and "plan" in o["pwt_tiled_tjds"]
+    assert "csr_vs_reference_report" not in lines[0]      # no GPU-over-reference ratio on the in-kernel clock any more
 
 
 # --------------------------------------------------- device-side format conversion
@@ -1215,6 +1261,86 @@ def test_sharded_unequal_blocks_on_several_gpus(torch, ngpus):
                 got[gather] = S.get_y(0, gathered=True)
                 S.close()
             assert np.array_equal(got[sm.GATHER_OVERLAPPED], got[sm.GATHER_AFTER])    # the same bits either way
+
+
+@pytest.mark.parametrize("ranks", [2, 4, 8])
+def test_sharded_virtual_ranks_on_one_gpu(torch, ranks):
+    """The N-GPU code of the C layer with N ranks sharing this box's one GPU (SMVP_EXCHANGE_COPIES: the all-gather as
+    device-to-device copies between the issuing threads): rows % N != 0, more ranks than rows, empty chunks, every rank's
+    gathered y against the oracle, both exchange forms bit-equal, CSR and TJDS, several products back to back (the wire
+    buffers are reused), power iteration, the column sweep on zero-row chunks, an early destroy."""
+    rng = np.random.default_rng(100 + ranks)
+    devices = [0] * ranks
+    for rows, cols, chunks in ((1003, 997, 3), (max(1, ranks - 1), 5, 2), (257, 257, 1)):
+        lens = [min(int(l), cols) for l in rng.integers(0, 9, rows)]
+        row_ptr, col_ind, val = csr_from_lengths(rng, lens, cols)
+        coo = sm.make_coo(np.repeat(np.arange(rows), lens), col_ind, val)
+        x = rng.random(cols)
+        ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+        scale = row_scale(row_ptr, col_ind, val, x)
+        for fmt in ("csr", "tjds"):
+            got = {}
+            for gather in (sm.GATHER_OVERLAPPED, sm.GATHER_AFTER):
+                S = sm.ShardedMatrix(fmt, ranks, rows, cols, coo=coo, csr=(row_ptr, col_ind, val), devices=devices, chunks=chunks,
+                                     exchange=sm.EXCHANGE_COPIES)
+                n, tallest = S.info()
+                c, bounds, cb = S.layout()
+                assert n == ranks and c == chunks and bounds[0] == 0 and bounds[-1] == rows and np.all(np.diff(bounds) >= 0)
+                S.set_x(x)
+                for _ in range(3):                      # back to back: the wire buffers are written again
+                    S.spmv(allgather=gather)
+                S.synchronize()
+                for slot in range(ranks):
+                    assert_close(S.get_y(slot, gathered=True), ref, scale)
+                assert_close(S.get_y(0, gathered=False), ref, scale)
+                got[gather] = S.get_y(ranks - 1, gathered=True)
+                if fmt == "csr" and gather == sm.GATHER_AFTER:
+                    S.set_csr_kernel(sm.CSR_KERNEL_COLSWEEP, 1024)      # zero-row chunks included
+                    S.spmv(allgather=gather)
+                    S.synchronize()
+                    assert_close(S.get_y(0, gathered=True), ref, scale)
+                S.close()
+            assert np.array_equal(got[sm.GATHER_OVERLAPPED], got[sm.GATHER_AFTER])    # the same bits either way
+    # power iteration: the gathered y is the next operand on every rank
+    m, n, coo = load("ibm32.mtx")
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    S = sm.ShardedMatrix("csr", ranks, m, n, csr=(row_ptr, col_ind, val), devices=devices, chunks=2, exchange=sm.EXCHANGE_COPIES)
+    S.set_x(None)
+    v = np.ones(n)
+    for _ in range(4):
+        S.spmv(allgather=sm.GATHER_OVERLAPPED)
+        S.feed_back(normalize=False)
+        v = ob.csr_spmv(row_ptr, col_ind, val, v)
+    S.synchronize()
+    assert np.array_equal(S.get_y(ranks - 1, gathered=True), v)        # pattern matrix: exact
+    S.close()
+    # early destroy with work in flight; and through the reference-shaped entry points
+    S = sm.ShardedMatrix("tjds", ranks, m, n, coo=coo, devices=devices, exchange=sm.EXCHANGE_COPIES)
+    S.set_x(None)
+    S.spmv(allgather=sm.GATHER_OVERLAPPED)
+    S.close()
+    y1, ms, st = sm.csr_compute(coo, m, n, iters=5, ngpus=ranks, exchange=sm.EXCHANGE_COPIES)
+    y2, _, _ = sm.tjds_compute(coo, m, n, iters=5, ngpus=ranks, exchange=sm.EXCHANGE_COPIES)
+    want = ob.csr_spmv(row_ptr, col_ind, val, np.ones(n))
+    assert np.array_equal(y1, want) and np.array_equal(y2, want) and len(ms) == 5 and st.time_min > 0
+    # RCCL cannot put two ranks on one device: refused, not hung
+    with pytest.raises(sm.SmvpError):
+        sm.ShardedMatrix("csr", 2, m, n, csr=(row_ptr, col_ind, val), devices=[0, 0])
+
+
+def test_cli_virtual_gpus(torch, tmp_path):
+    """--gpus 4 --virtual-gpus on the one-GPU box: the reports equal the committed ones."""
+    out = tmp_path / "virt"
+    out.mkdir()
+    p = subprocess.run([sm.CLI_PATH, "-c", "-t", "-n", "20", "--gpus", "4", "--virtual-gpus", "-d", str(out), ob.fixture_path("ibm32.mtx")],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "4 virtual GPUs" in p.stdout
+    for alg, stamp in (("CSR", REPORTS["ibm32.mtx"][0]), ("TJDS", REPORTS["ibm32.mtx"][1])):
+        files = [f for f in os.listdir(out) if "_%s_" % alg in f]
+        assert len(files) == 1
+        got = ob.report_y_lines(open(os.path.join(out, files[0])).read())
+        assert got == ob.report_y_lines(ob.read_report("smvp-toolbox_report_%s_%s.txt" % (alg, stamp)))
 
 
 def test_sharded_issuing_thread_machinery_on_one_gpu(torch, tmp_path):
