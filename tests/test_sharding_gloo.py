@@ -132,3 +132,20 @@ def test_bounds_helpers():
     counts, pad = sharding.gather_counts(b)
     assert counts.tolist() == [2, 3, 2, 3] and pad == 3
     assert sharding.equal_row_bounds(1 << 24, 8).tolist() == [(1 << 21) * g for g in range(9)]
+
+
+def test_choose_chunks_model():
+    """Chunks per rank from measured product times and the two link models (or a measured gather): more chunks hide more of
+    the exchange but the column sweep pays for each of them -- DESIGN 6's numbers for one rank's eighth of config 4."""
+    pick = sharding.choose_chunks({1: 0.41, 2: 0.44, 4: 0.54}, 8 * 1.25e6, 8)
+    assert pick["chosen"] == 2 and pick["inputs"]["gather_ms_by_chunks"] is None
+    e = pick["estimates_ms"]
+    assert e[1]["direct_links"] < e[4]["direct_links"] and e[4]["one_link_ring"] < e[1]["one_link_ring"]      # each model has its own favourite
+    assert abs(e[1]["one_link_ring"] - (0.41 + 7 * 10e6 / 153e9 * 1e3)) < 1e-3
+    # a measured gather decides alone; free chunks (a product that does not slow down) -> as many as offered when the gather is slow
+    assert sharding.choose_chunks({1: 1.0, 2: 1.0, 4: 1.0}, 8e6, 2, {1: 0.8, 2: 0.4, 4: 0.2})["chosen"] == 4
+    assert sharding.choose_chunks({1: 1.0, 2: 1.3, 4: 1.9}, 8e6, 2, {1: 0.1, 2: 0.05, 4: 0.03})["chosen"] == 1
+    # one GPU: nothing to gather, one chunk
+    assert sharding.choose_chunks({1: 0.4, 2: 0.5}, 8e6, 1)["chosen"] == 1
+    assert sharding.overlapped_step_ms(0.4, 4, 0.3) == pytest.approx(0.1 + 4 * 0.3)       # gathers queue behind each other
+    assert sharding.overlapped_step_ms(0.4, 4, 0.05) == pytest.approx(0.4 + 0.05)         # only the last one is exposed

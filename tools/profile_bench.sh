@@ -10,14 +10,20 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p "$OUT"
 ARGS="--no-live-traffic --no-c-layer --no-random-model --no-tjds --no-cpu-baseline --no-samples --no-config4 --no-pwt-tiled ${BENCH_ARGS:-}"
-PAT=${PAT:-csr_stream_owner<8, 5}   # kernel-name substring the PMC summary is taken over
+PAT=${PAT:-csr_stream_owner<8, 5}   # kernel-name substring the PMC summary is taken over; several, separated by '|', for a product of
+                                    # several kernels (the binned plan): their per-launch means are added
 python3 $R/bench.py --steps 100 --warmup 10 $ARGS > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "bench failed"; tail -5 "$OUT/bench.err"; exit 1; }
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 $R/bench.py --steps 100 --warmup 10 $ARGS > "$OUT/trace.log" 2>&1 || echo "kernel-trace pass failed"
 cp "$OUT/trace/t_kernel_stats.csv" "$OUT/kernel_stats.csv" 2>/dev/null
 cd $R
 bash tools/pmc_passes.sh gpurun_out/profile_$TAG/pmc -- python3 $R/bench.py --steps 10 --warmup 2 $ARGS > /dev/null
-python3 tools/pmc_summary.py "$OUT/pmc" "$PAT" > "$OUT/pmc_summary.txt"
+: > "$OUT/pmc_summary.txt"
+IFS='|' read -ra PATS <<< "$PAT"
+for P1 in "${PATS[@]}"; do
+  echo "== $P1" >> "$OUT/pmc_summary.txt"
+  python3 tools/pmc_summary.py "$OUT/pmc" "$P1" >> "$OUT/pmc_summary.txt"
+done
 python3 - "$OUT" <<'PY'
 import json, re, sys
 out = sys.argv[1]
@@ -25,13 +31,13 @@ vals = {}
 for line in open(out + "/pmc_summary.txt"):
     m = re.match(r"(\S+)\s+mean\s+([\d.]+)", line)
     if m:
-        vals[m.group(1)] = float(m.group(2))
+        vals[m.group(1)] = vals.get(m.group(1), 0.0) + float(m.group(2))     # summed over the product's kernels
 bench = json.loads(open(out + "/bench.json").read().strip().splitlines()[-1])
 fetch, write = vals.get("FETCH_SIZE"), vals.get("WRITE_SIZE")
 t = {"workload": bench["config"]["workload"], "kernel": bench["roofline"]["kernel"],
      "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
      "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024.0 if fetch and write else None,
-     "alg_bytes_per_launch": bench["roofline"]["alg_bytes_per_launch"],
+     "alg_bytes_per_launch": bench["roofline"]["alg_bytes_per_launch"] * (bench["roofline"].get("launches_per_product", 1) if " + " in bench["roofline"]["kernel"] else 1),
      "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B read requests at 64 B), WRITE_SIZE as read",
      "counters": vals}
 if t["traffic_bytes_per_launch"]:
