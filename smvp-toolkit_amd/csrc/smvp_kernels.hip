@@ -361,6 +361,18 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     double v[VPT];
     const bool full_tile = s + TILE <= (long long)nnz;
     int grp[HALF ? VPT : 1];  // TjdsH: run (inside the tile) of the first entry of this entry's group of 32
+    // TjdsH: the tile's run table (start_pos of each run's diagonal), one entry per lane, requested with the tile's own streams:
+    // an entry then takes its run's base from its wavefront's copy by a cross-lane read instead of a second, dependent
+    // trip to memory in front of the x gather (tiles with more than 64 runs read the rest as before)
+    int run0 = 0, run_tbl = 0;
+    if constexpr (HALF) {
+        if (full_tile) {
+            run0 = ex.run_ptr[b];
+            const int nruns = ex.run_ptr[b + 1] - run0;
+            const int ln = t & 63;
+            run_tbl = ln < nruns ? ex.run_sp[run0 + ln] : 0;
+        }
+    }
     if constexpr (HALF) {
         if (full_tile) {
 #pragma unroll
@@ -466,15 +478,15 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
         }
         if (full_tile) {
             int slot[VPT];
-            int run0 = 0;
-            if constexpr (HALF)
-                run0 = ex.run_ptr[b];
 #pragma unroll
             for (int k = 0; k < VPT; ++k) {
                 slot[k] = c[k] & ((1 << kSlotBits) - 1);
                 if constexpr (HALF) {
                     const int r = grp[k] + (((c[k] >> kSlotBits) - grp[k]) & 31);
-                    c[k] = pj[k] - ex.run_sp[run0 + r];
+                    int sp = __shfl(run_tbl, r & 63);
+                    if (r >= 64)
+                        sp = ex.run_sp[run0 + r];
+                    c[k] = pj[k] - sp;
                 } else {
                     c[k] = pj[k] - a.start_pos[(unsigned)c[k] >> kSlotBits];
                 }
