@@ -1316,6 +1316,14 @@ def main():
     headline_roofline["others"] = others
 
     if rank == 0:
+        # what this process leaves behind: its children (the rocprofv3 --pmc passes, the C-layer child) have been waited for;
+        # BENCH_r02 / r03 counted one process at the end of the run -- not one of these (none is left)
+        try:
+            import psutil
+            kids = psutil.Process().children(recursive=True)
+            extra["child_processes_at_exit"] = [" ".join(k.cmdline())[:120] for k in kids if k.is_running()]
+        except Exception:
+            extra["child_processes_at_exit"] = None
         line = {
             "metric": "fp64 %s SpMV GFLOP/s (2*nnz flop per product; achieved HBM GB/s in roofline)" % args.format.upper() +
                       ("; step = local product + RCCL all-gather of y on the headline matrix (strong scaling); the curve BASELINE.md "

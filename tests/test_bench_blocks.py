@@ -62,3 +62,24 @@ def test_host_check_catches_a_wrong_row():
     bad = good.copy()
     bad[123] += 1e-6 * scale[123]
     assert not bench.host_check(blk, x, bad)[0]
+
+
+def test_c_layer_child_is_given_up_on_when_it_hangs(tmp_path, monkeypatch):
+    """N > 1: bench.py runs the C-layer leg in a child process of rank 0 under a wall-clock budget -- a hang there must cost
+    that leg ({"error": "timeout"}), not the run; a child that dies reports its last line; a child that answers is parsed."""
+    import json
+    import time
+
+    def child(body):
+        f = tmp_path / "child.py"
+        f.write_text(body)
+        monkeypatch.setattr(bench.os.path, "abspath", lambda p: str(f) if str(p).endswith("bench.py") else p)
+        return bench.c_layer_in_child(argparse.Namespace(rows=1000, c_layer_budget=1.5), 8, 5, rank=1)
+
+    t0 = time.time()
+    out = child("import time\ntime.sleep(60)\n")
+    assert out["error"] == "timeout" and out["n_gpus"] == 8 and time.time() - t0 < 20
+    out = child("import sys\nprint('no GPU here', file=sys.stderr)\nsys.exit(3)\n")
+    assert "error" in out and "3" in out["error"]
+    out = child("import json\nprint(json.dumps({'n_gpus': 8, 'chunks_1': {'overlapped': {'event_ms': 1.0}}}))\n")
+    assert out["n_gpus"] == 8 and "child process of rank 0" in out["ran_in"] and out["chunks_1"]["overlapped"]["event_ms"] == 1.0
