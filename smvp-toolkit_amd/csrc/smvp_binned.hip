@@ -85,20 +85,26 @@ template <int G>
 __global__ __launch_bounds__(kBinThreads) void csr_binned_far_products(
     const double *__restrict__ x, int cols, const double *__restrict__ a_val, const unsigned short *__restrict__ a_word,
     const int *__restrict__ a_chunk, const int *__restrict__ a_ptr, const int *__restrict__ a_shift_ptr,
-    const int *__restrict__ a_shift, double *__restrict__ bins, int splits)
+    const int *__restrict__ a_shift, double *__restrict__ bins, int splits, int items)
 {
     extern __shared__ double lds[];
     double *xs = lds;
     int *shift = reinterpret_cast<int *>(lds + (1 << kBinColBits));
-    const int cb = (int)blockIdx.x / splits, part = (int)blockIdx.x % splits;
+    const int t = threadIdx.x;
+    // one work item = (column block, part of its stream); a workgroup takes items blockIdx.x, + gridDim.x, ...: the launch
+    // gives every item its own workgroup (a grid of one persistent workgroup per CU was tried to share the CUs with the
+    // near product: no gain, see the engine)
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    if (item != (int)blockIdx.x)
+        __syncthreads();  // everybody has left the previous item's block of x
+    const int cb = item / splits, part = item % splits;
     const int a = a_ptr[cb], z = a_ptr[cb + 1];  // multiples of 256
     // with few column blocks every block's stream is cut into `splits` runs of whole groups, one workgroup each
     const int groups = (z - a) >> 8, per = (groups + splits - 1) / splits;
     const int pa = a + 256 * (part * per < groups ? part * per : groups);
     const int pz = a + 256 * ((part + 1) * per < groups ? (part + 1) * per : groups);
     if (pa >= pz)
-        return;
-    const int t = threadIdx.x;
+        continue;
     const long long c0 = (long long)cb << kBinColBits;
     if (c0 + (1 << kBinColBits) <= (long long)cols) {
         for (int i = 2 * t; i < (1 << kBinColBits); i += 2 * kBinThreads)
@@ -110,27 +116,35 @@ __global__ __launch_bounds__(kBinThreads) void csr_binned_far_products(
     const int sp = a_shift_ptr[cb], ncell = a_shift_ptr[cb + 1] - sp;
     for (int i = t; i < ncell && i < kBinShiftCap; i += kBinThreads)
         shift[i] = a_shift[sp + i];
-    __syncthreads();
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);  // (uniform: the chunk counts become scalar loads)
     const unsigned long long le = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1);
-    for (int base = pa + wave * 256 * G; base < pz; base += (kBinThreads / 64) * 256 * G) {
-        double2v v[2 * G];
-        uint2v w[G];
-        int4 cc[G];
+    // Software-pipelined: a wavefront's next groups are requested before its current ones are multiplied and stored, and
+    // the first ones before the barrier behind which the block of x stands in LDS (they do not depend on it).
+    constexpr int STEP = (kBinThreads / 64) * 256 * G;
+    double2v v[2 * G], vn[2 * G];
+    uint2v w[G], wn[G];
+    int4 cc[G], cn[G];
+    auto load = [&](int base, double2v (&vv)[2 * G], uint2v (&ww)[G], int4 (&cw)[G]) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int b = base + 256 * g;
             if (b < pz) {
-                v[2 * g] = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(a_val + b) + lane);
-                v[2 * g + 1] = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(a_val + b + 128) + lane);
-                w[g] = __builtin_nontemporal_load(reinterpret_cast<const uint2v *>(a_word + b) + lane);
-                cc[g] = *reinterpret_cast<const int4 *>(a_chunk + (b >> 6));
+                vv[2 * g] = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(a_val + b) + lane);
+                vv[2 * g + 1] = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(a_val + b + 128) + lane);
+                ww[g] = __builtin_nontemporal_load(reinterpret_cast<const uint2v *>(a_word + b) + lane);
+                cw[g] = *reinterpret_cast<const int4 *>(a_chunk + (b >> 6));
             } else {
-                v[2 * g] = v[2 * g + 1] = double2v{0.0, 0.0};
-                w[g] = uint2v{0xffffffffu, 0xffffffffu};
-                cc[g] = make_int4(0, 0, 0, 0);
+                vv[2 * g] = vv[2 * g + 1] = double2v{0.0, 0.0};
+                ww[g] = uint2v{0xffffffffu, 0xffffffffu};
+                cw[g] = make_int4(0, 0, 0, 0);
             }
         }
+    };
+    int base = pa + wave * 256 * G;
+    load(base, v, w, cc);
+    __syncthreads();
+    for (; base < pz; base += STEP) {
+        load(base + STEP, vn, wn, cn);  // (past the end: nothing is read)
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int wk[4] = {(int)(w[g].x & 0xffffu), (int)(w[g].x >> 16), (int)(w[g].y & 0xffffu), (int)(w[g].y >> 16)};
@@ -149,7 +163,14 @@ __global__ __launch_bounds__(kBinThreads) void csr_binned_far_products(
                 }
             }
         }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            v[2 * g] = vn[2 * g], v[2 * g + 1] = vn[2 * g + 1];
+            w[g] = wn[g];
+            cc[g] = cn[g];
+        }
     }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -866,8 +887,9 @@ hipError_t launch_binned_products(const BinnedPlan &p, const double *x, hipStrea
     hipError_t e = ask_for_lds();
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(csr_binned_far_products<2>, dim3((unsigned)p.ncb * (unsigned)p.splits), dim3(kBinThreads), kLdsA, stream, x, p.cols,
-                       p.a_val, p.a.word, p.a.chunk, p.a.ptr, p.a.shift_ptr, p.a.shift, p.bins, p.splits);
+    const int items = p.ncb * p.splits;
+    hipLaunchKernelGGL(csr_binned_far_products<2>, dim3((unsigned)items), dim3(kBinThreads), kLdsA, stream, x, p.cols,
+                       p.a_val, p.a.word, p.a.chunk, p.a.ptr, p.a.shift_ptr, p.a.shift, p.bins, p.splits, items);
     return hipGetLastError();
 }
 

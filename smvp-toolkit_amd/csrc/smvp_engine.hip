@@ -727,9 +727,11 @@ static int csr_spmv_impl(smvp_csr_t *h, const double *d_x, double *d_y, void *st
     hipError_t e;
     if (h->kernel == SMVP_CSR_KERNEL_BINNED) {
         // the near part writes every row of y; pass A puts the far products into the bins; pass B adds each row's far sum.
-        // (Pass A needs x only and was tried on a stream of its own beside the near product: its one workgroup per CU --
-        // 132 KB of LDS -- only gets onto a CU once the tile kernel's six have drained, so the two ran one after the other
-        // anyway: 0.777 against 0.757 ms, profiles/r04_binned_measured.txt.)
+        // (Pass A needs x only and was tried beside the near product, twice.  On a stream of its own its one workgroup per
+        // CU -- 132 KB of LDS -- only got onto a CU once the tile kernel's six had drained: one after the other anyway,
+        // 0.777 against 0.757 ms.  As one persistent workgroup per CU enqueued AHEAD of the near product the two did share
+        // the CUs -- and pass A then took 264 instead of 238 us while the near product finished 241 us after it instead of
+        // 303: 0.7485 against 0.7540 ms.  What one gains the other loses: profiles/r04_binned_measured.txt.)
         if (int rc = csr_spmv_impl(h->near, d_x, d_y, stream, nullptr))
             return rc;
         e = smvp::launch_binned_products(h->bin, d_x, st);

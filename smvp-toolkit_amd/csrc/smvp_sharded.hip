@@ -582,8 +582,16 @@ int issue_product(smvp_sharded *h, size_t g, int allgather, int timed)
         HIP_TRY(hipEventRecord(h->ev0[g], h->stream[g]));
     const bool copies = h->exchange == SMVP_EXCHANGE_COPIES;
     const size_t n = (size_t)h->n;
+    bool placed_awaited[2] = {false, false};  // per stream the copies go on: [0] the compute stream, [1] the exchange stream
     auto gather = [&](size_t c, hipStream_t st) -> int {
         if (copies) {  // this rank's piece of chunk c into every rank's wire buffer
+            if (!placed_awaited[st == h->stream[g] ? 0 : 1]) {
+                // ... once every rank has read the previous product's pieces out of its wire buffer (ev_placed: recorded
+                // by all of them before anybody left that product, see below)
+                for (size_t r = 0; r < n; ++r)
+                    HIP_TRY(hipStreamWaitEvent(st, h->ev_placed[r], 0));
+                placed_awaited[st == h->stream[g] ? 0 : 1] = true;
+            }
             for (size_t r = 0; r < n; ++r)
                 HIP_TRY(hipMemcpyAsync(h->d_wire[r] + h->woff[c] + g * (size_t)h->pad[c], h->d_y_local[g] + h->loff[c],
                                        sizeof(double) * (size_t)h->pad[c], hipMemcpyDeviceToDevice, st));
