@@ -705,6 +705,7 @@ void free_binned_plan(BinnedPlan *p)
             (void)hipFree(q);
     free_stream(&p->a);
     free_stream(&p->b);
+    free_near_window(&p->nw);
     *p = BinnedPlan();
 }
 
@@ -729,8 +730,17 @@ int csr_far_share(const int *d_row_ptr, const int *d_col_ind, int rows, int nnz,
     return SMVP_OK;
 }
 
+// capped[r] = row r has more than `cap` far entries (before the cap is applied: fpos from the first scan)
+__global__ __launch_bounds__(256) void bin_capped_rows(const int *__restrict__ row_ptr, const int *__restrict__ fpos, int rows, int cap,
+                                                       int *__restrict__ capped)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < rows)
+        capped[r] = fpos[row_ptr[r + 1]] - fpos[row_ptr[r]] > cap ? 1 : 0;
+}
+
 int build_binned_plan(const int *d_row_ptr, const int *d_col_ind, const double *d_val, int rows, int cols, int nnz, int band,
-                      BinnedPlan *out, hipStream_t st)
+                      bool near_window, BinnedPlan *out, hipStream_t st)
 {
     free_binned_plan(out);
     BinnedPlan &P = *out;
@@ -768,6 +778,9 @@ int build_binned_plan(const int *d_row_ptr, const int *d_col_ind, const double *
     HIP_TRY(hipGetLastError());
     if (int rc = scan_exclusive(flag, fpos, (size_t)nnz + 1, sc, st))
         return rc;
+    int *capped;
+    HIP_TRY(sc.get(&capped, (size_t)rows + 1));
+    hipLaunchKernelGGL(bin_capped_rows, dim3(blocks_for(rows)), dim3(256), 0, st, d_row_ptr, fpos, rows, P.slots / 8, capped);
     hipLaunchKernelGGL(bin_cap_rows, dim3(blocks_for(nnz)), dim3(256), 0, st, d_row_ptr, fpos, rows, P.slots / 8, row_of, nnz, flag);
     HIP_TRY(hipGetLastError());
     if (int rc = scan_exclusive(flag, fpos, (size_t)nnz + 1, sc, st))
@@ -795,9 +808,24 @@ int build_binned_plan(const int *d_row_ptr, const int *d_col_ind, const double *
                        P.near_val, f_col, f_val, f_row);
     hipLaunchKernelGGL(bin_row_ptrs, dim3(blocks_for((long long)rows + 1)), dim3(256), 0, st, d_row_ptr, fpos, rows, frp, P.near_ptr, has);
     HIP_TRY(hipGetLastError());
+    // the near part's window plan, where it suits: the near arrays are then not needed any more
+    auto window = [&]() -> int {
+        if (!near_window)
+            return SMVP_OK;
+        if (int rc = build_near_window(P.near_ptr, P.near_col, P.near_val, capped, rows, cols, P.nnz_near, P.band, &P.nw, st))
+            return rc;
+        if (P.nw.on) {
+            (void)hipFree(P.near_col);
+            (void)hipFree(P.near_val);
+            P.near_col = nullptr, P.near_val = nullptr;
+            P.plan_bytes -= (size_t)P.nnz_near * (sizeof(int) + sizeof(double));
+            P.plan_bytes += P.nw.plan_bytes;
+        }
+        return SMVP_OK;
+    };
     if (nf == 0) {
         HIP_TRY(hipStreamSynchronize(st));
-        return SMVP_OK;  // nothing is far: the near part is the whole matrix
+        return window();  // nothing is far: the near part is the whole matrix
     }
     // ---- far rows and row blocks
     if (int rc = scan_exclusive(has, kpos, (size_t)rows + 1, sc, st))
@@ -856,7 +884,7 @@ int build_binned_plan(const int *d_row_ptr, const int *d_col_ind, const double *
     hipLaunchKernelGGL(bin_block_desc, dim3(blocks_for(P.nrb)), dim3(256), 0, st, P.b.ptr, P.b.shift_ptr, P.blk_fr, P.fr_ptr, P.nrb, P.b_desc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
-    return SMVP_OK;
+    return window();
 }
 
 // more than 64 KB of dynamic LDS must be asked for, once per device

@@ -633,12 +633,18 @@ static double wall_ms()
     return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
 }
 
-// The binned plan: near / far split on the device, the near part behind a nested handle that stays on the tile kernels.
+// The binned plan: near / far split on the device; the near part as the window plan (smvp_near_window.hip) where that suits,
+// else behind a nested handle that stays on the tile kernels.
 static int build_binned(smvp_csr *h, int band)
 {
     free_binned(h);
-    if (int rc = smvp::build_binned_plan(h->d_row_ptr, h->d_col_ind, h->d_val, h->rows, h->cols, h->nnz, band, &h->bin, nullptr))
+    bool window = true;
+    if (const char *e = getenv("SMVP_BINNED_NEAR"))  // development switch (plan time): "tile" keeps the near part on the tile kernel
+        window = strcmp(e, "tile") != 0;
+    if (int rc = smvp::build_binned_plan(h->d_row_ptr, h->d_col_ind, h->d_val, h->rows, h->cols, h->nnz, band, window, &h->bin, nullptr))
         return rc;
+    if (h->bin.nw.on)
+        return SMVP_OK;
     return csr_create_impl(&h->near, h->device, h->rows, h->cols, h->bin.nnz_near, h->bin.near_ptr, h->bin.near_col, h->bin.near_val,
                            SMVP_MEM_DEVICE, nullptr, smvp::kFlavorCsr, nullptr, true);
 }
@@ -718,7 +724,7 @@ static int csr_spmv_impl(smvp_csr_t *h, const double *d_x, double *d_y, void *st
 {
     if (!h || (h->rows > 0 && !d_y) || (h->nnz > 0 && !d_x))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_spmv: bad argument");
-    if ((h->kernel == SMVP_CSR_KERNEL_COLSWEEP && !h->d_sweep_ptr) || (h->kernel == SMVP_CSR_KERNEL_BINNED && !h->near) ||
+    if ((h->kernel == SMVP_CSR_KERNEL_COLSWEEP && !h->d_sweep_ptr) || (h->kernel == SMVP_CSR_KERNEL_BINNED && !h->near && !h->bin.nw.on) ||
         (h->kernel != SMVP_CSR_KERNEL_VECTOR && h->kernel != SMVP_CSR_KERNEL_COLSWEEP && h->kernel != SMVP_CSR_KERNEL_BINNED &&
          !h->d_tile_row))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_spmv: the handle has no launch plan (a re-plan failed earlier)");
@@ -732,7 +738,11 @@ static int csr_spmv_impl(smvp_csr_t *h, const double *d_x, double *d_y, void *st
         // 0.777 against 0.757 ms.  As one persistent workgroup per CU enqueued AHEAD of the near product the two did share
         // the CUs -- and pass A then took 264 instead of 238 us while the near product finished 241 us after it instead of
         // 303: 0.7485 against 0.7540 ms.  What one gains the other loses: profiles/r04_binned_measured.txt.)
-        if (int rc = csr_spmv_impl(h->near, d_x, d_y, stream, nullptr))
+        if (h->bin.nw.on) {
+            e = smvp::launch_near_window(h->bin.nw, d_x, d_y, st);
+            if (e != hipSuccess)
+                return smvp::fail(SMVP_ERR_HIP, "CSR launch failed: %s", hipGetErrorString(e));
+        } else if (int rc = csr_spmv_impl(h->near, d_x, d_y, stream, nullptr))
             return rc;
         e = smvp::launch_binned_products(h->bin, d_x, st);
         if (e != hipSuccess)
@@ -779,7 +789,10 @@ extern "C" int smvp_csr_describe(const smvp_csr_t *h, char *kernel_name, size_t 
     if (!h)
         return smvp::fail(SMVP_ERR_INVALID, "null handle");
     if (kernel_name && cap) {
-        if (h->kernel == SMVP_CSR_KERNEL_BINNED)
+        if (h->kernel == SMVP_CSR_KERNEL_BINNED && h->bin.nw.on)
+            snprintf(kernel_name, cap, "csr_binned: csr_near_window + csr_binned_far_products<2> + csr_binned_far_sums<%d, %d, 2>", h->bin.slots,
+                     h->bin.threads_b);
+        else if (h->kernel == SMVP_CSR_KERNEL_BINNED)
             snprintf(kernel_name, cap, "csr_binned: csr_stream_owner<%d, %d, false> + csr_binned_far_products<2> + csr_binned_far_sums<%d, %d, 2>",
                      h->near ? h->near->vpt : 0, h->near ? (h->near->d_col16 ? smvp::kFlavorCsr16 : h->near->flavor) : 0,
                      h->bin.slots, h->bin.threads_b);
@@ -808,6 +821,8 @@ extern "C" int smvp_csr_plan_launches(const smvp_csr_t *h, int *launches)
         *launches = std::max(1, (nwg + h->sweep_per_launch - 1) / h->sweep_per_launch);
     } else if (h->kernel == SMVP_CSR_KERNEL_STREAM_CARRY && h->ntiles > 1) {
         *launches = 2;
+    } else if (h->kernel == SMVP_CSR_KERNEL_BINNED && h->bin.nw.on) {
+        *launches = 1 + (h->bin.nw.n_out > 0 ? 1 : 0) + (h->bin.nf > 0 ? 2 : 0);
     } else if (h->kernel == SMVP_CSR_KERNEL_BINNED && h->near) {
         int near = 1;
         (void)smvp_csr_plan_launches(h->near, &near);

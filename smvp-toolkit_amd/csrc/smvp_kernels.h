@@ -100,14 +100,44 @@ struct BinnedStream {
     int *shift = nullptr;            // cells
 };
 
+// ---- K6: the near part with a row block's window of x in LDS (smvp_near_window.hip) ----
+constexpr int kNwRowBlock = 8192;  // rows per workgroup
+constexpr int kNwBand = 4096;      // the window reaches this far to either side of the block's rows: 16384 columns = 128 KB of LDS
+constexpr int kNwShortCap = 16;    // a row of at most this many near entries is one lane of a slice; a longer one a slice of its own
+constexpr int kNwLongCap = 1024;   // long rows a block may hold (their list and their sums sit in LDS): more, and the plan does not suit
+struct NearWindow {
+    bool on = false;
+    int rows = 0, cols = 0, nblocks = 0, n_out = 0;
+    long long slots = 0;                           // entries of the streams (64 per step)
+    int *wave_ptr = nullptr;                       // nblocks * 16 + 1: first step of every wavefront's run
+    int *wave_n1 = nullptr, *wave_n2 = nullptr;    // steps of its short slices / of its long rows
+    unsigned short *perm16 = nullptr;              // nblocks * 8192: the block's rows, longest first (0xffff: not a short row)
+    double *sval = nullptr;                        // slots
+    unsigned short *sword = nullptr;               // slots: column inside the window | valid | last step of the slice
+    int *blk_long_ptr = nullptr;                   // nblocks + 1
+    unsigned short *long_row16 = nullptr;          // the long rows, block by block
+    int *out_row = nullptr, *out_ptr = nullptr, *out_col = nullptr;  // rows with entries outside the window: a CSR of their own
+    double *out_val = nullptr;
+    size_t plan_bytes = 0;
+};
+void free_near_window(NearWindow *p);
+// the near CSR arrays of a binned plan -> the window plan; `capped[r]` != 0 marks a row that keeps entries outside the band.
+// out->on stays false (and SMVP_OK is returned) where the plan does not suit: band > kNwBand, a block with too many long rows
+int build_near_window(const int *near_ptr, const int *near_col, const double *near_val, const int *capped, int rows, int cols,
+                      int nnz_near, int band, NearWindow *out, hipStream_t stream);
+// y[r] = the near part's sum for EVERY row r (0 without near entries)
+hipError_t launch_near_window(const NearWindow &p, const double *x, double *y, hipStream_t stream);
+
 struct BinnedPlan {
     int band = kBinNearBand;
     int rows = 0, cols = 0, nnz = 0, nnz_near = 0, nf = 0;  // nf: far entries
     int ncb = 0, nrb = 0, q = 1, nfr = 0, splits = 1;       // column blocks, row blocks, row blocks per super block, far rows
     int slots = kBinSlots, threads_b = kBinThreads;          // pass B: far entries per row block at most (a row's cap is an eighth of it), threads per workgroup
-    // near part: its own CSR arrays (rows + 1, nnz_near, nnz_near), run by the tile kernel
+    // near part: its own CSR arrays (rows + 1, nnz_near, nnz_near), run by the tile kernel -- or, where it suits, the window
+    // plan `nw` built from them (the arrays are then released)
     int *near_ptr = nullptr, *near_col = nullptr;
     double *near_val = nullptr;
+    NearWindow nw;
     // far part
     double *a_val = nullptr;   // pass A stream: values (a.padded)
     BinnedStream a, b;
@@ -118,8 +148,9 @@ struct BinnedPlan {
 };
 void free_binned_plan(BinnedPlan *p);
 // near / far split of a device-resident CSR matrix and the far part's two streams, built on the device
+// near_window: build the near part's window plan where it suits (out->nw.on tells)
 int build_binned_plan(const int *d_row_ptr, const int *d_col_ind, const double *d_val, int rows, int cols, int nnz, int band,
-                      BinnedPlan *out, hipStream_t stream);
+                      bool near_window, BinnedPlan *out, hipStream_t stream);
 // far products into the bins (pass A: needs x only); y[row] += the row's far sum for every row with far entries (pass B:
 // after pass A, and after the near product has written y)
 hipError_t launch_binned_products(const BinnedPlan &p, const double *x, hipStream_t stream);

@@ -262,11 +262,13 @@ def test_colsweep_rows_that_meet_in_a_chunk(torch):
         assert np.array_equal(y, ref)
 
 
-def test_binned_plan_on_the_random_model(torch):
-    """SURVEY 8(d)'s memplus-shaped random model (2^22 rows here): AUTO picks the binned plan -- near part on the tile
-    kernel, far part through the LDS-binned passes; the result is within the normwise bound of the serial loop, the
-    same bits from run to run, equal to the serial loop's bits on every short row without far entries; the plan's
-    size is what smvp_csr_plan_info says."""
+@pytest.mark.parametrize("near", ["window", "tile"])
+def test_binned_plan_on_the_random_model(torch, monkeypatch, near):
+    """SURVEY 8(d)'s memplus-shaped random model (2^22 rows here): AUTO picks the binned plan -- near part with a row
+    block's window of x in LDS (or, SMVP_BINNED_NEAR=tile at plan time, on the tile kernel), far part through the
+    LDS-binned passes; the result is within the normwise bound of the serial loop, the same bits from run to run, equal
+    to the serial loop's bits on every short row without far entries; the plan's size is what smvp_csr_plan_info says."""
+    monkeypatch.setenv("SMVP_BINNED_NEAR", near)
     rows = 1 << 22
     row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_MEMPLUS_SHAPED, 12345, rows, rows)
     x = sm.vector_random(rows)
@@ -275,7 +277,8 @@ def test_binned_plan_on_the_random_model(torch):
     A = sm.CsrMatrix(rows, rows, row_ptr, col_ind, val)
     assert A.get_kernel() == (sm.CSR_KERNEL_BINNED, 4096) and A.launches() == 3
     name, alg = A.describe()
-    assert name.startswith("csr_binned: csr_stream_owner<") and "csr_binned_far_products" in name and "csr_binned_far_sums" in name
+    assert name.startswith("csr_binned: csr_near_window + " if near == "window" else "csr_binned: csr_stream_owner<")
+    assert "csr_binned_far_products" in name and "csr_binned_far_sums" in name
     assert alg == 12.0 * len(val) + 4.0 * (rows + 1) + 16.0 * rows
     dx = dev(torch, x)
     ys = []
@@ -289,14 +292,16 @@ def test_binned_plan_on_the_random_model(torch):
     rows_of = np.repeat(np.arange(rows), np.diff(row_ptr))
     far = np.abs(col_ind.astype(np.int64) - rows_of) > 4096
     has_far = np.bincount(rows_of[far], minlength=rows) > 0
-    short = np.diff(row_ptr) <= 32
+    short = np.diff(row_ptr) <= 16               # (the window plan sums a longer row across a wavefront)
     assert 0.3 < far.mean() < 0.5 and (short & ~has_far).sum() > 1000
     assert np.array_equal(ys[0][short & ~has_far], ref[short & ~has_far])
     info = A.plan_info()
     n, nf = len(val), int(far.sum())
     assert info["matrix_bytes"] == 12.0 * n + 4.0 * (rows + 1)
-    # near copy 12 B (+ 2 B of column offsets) per near entry, 20 B per far entry (two streams + the bins), 16 B per far row
-    assert 12.0 * (n - nf) + 20.0 * nf < info["plan_bytes"] < 14.5 * (n - nf) + 21.0 * nf + 24.0 * rows and info["build_ms"] > 0
+    # near copy 12 B (+ 2 B of column offsets) per near entry on the tile kernel, 10 B per slot (entries + 11 % padding) and
+    # 2 B per row in the window plan; 20 B per far entry (two streams + the bins), 16 B per far row
+    lo = 12.0 if near == "tile" else 10.0
+    assert lo * (n - nf) + 20.0 * nf < info["plan_bytes"] < 14.5 * (n - nf) + 21.0 * nf + 24.0 * rows and info["build_ms"] > 0
     # the tile kernel on the same handle: the same product
     A.set_kernel(sm.CSR_KERNEL_STREAM, 0)
     dy = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
@@ -350,6 +355,80 @@ def test_binned_plan_corner_structures(torch):
     x = rng.random(cols)
     y = gpu_csr(torch, rows, cols, row_ptr, col_ind, val, x, sm.CSR_KERNEL_BINNED, 16)
     assert_close(y, ob.csr_spmv(row_ptr, col_ind, val, x), row_scale(row_ptr, col_ind, val, x))
+
+
+def test_binned_near_engines(torch, monkeypatch):
+    """The near part's two engines -- the window plan (a row block's window of x in LDS, rows sorted by length, long rows
+    summed by a wavefront) and the tile kernel -- against the oracle on structures that stress the window plan: several
+    row blocks with a ragged last one, rows of 0 ... 16 (lanes of a slice), 17 ... 300 (slices of their own) entries, empty
+    stretches, columns at the window's edges, a rectangular matrix with fewer columns than rows, rows that keep their far
+    entries near (outside the window), unaligned operands, more long rows in a block than the window plan takes (it then
+    stays on the tile kernel); the window plan's bits do not change from run to run."""
+    rng = np.random.default_rng(77)
+    cases = []
+    for rows, cols, band in ((20_000, 20_000, 0), (8192 * 2 + 77, 30_000, 4096), (9_000, 2_500, 100), (70_000, 70_000, 1)):
+        reach = band if band else 4096
+        lens = rng.choice([0, 1, 2, 3, 5, 8, 16, 17, 40, 300], rows, p=[.15, .2, .2, .15, .1, .08, .05, .03, .03, .01])
+        lens[rows // 3: rows // 3 + 700] = 0
+        row_of = np.repeat(np.arange(rows), lens)
+        off = rng.integers(-reach, reach + 1, row_of.size)
+        edge = rng.random(row_of.size) < 0.1
+        off[edge] = rng.choice([-reach, reach], int(edge.sum()))            # the window's last columns
+        col = np.clip(row_of + off, 0, cols - 1)
+        far = rng.random(row_of.size) < 0.15
+        col[far] = rng.integers(0, cols, int(far.sum()))                    # some entries anywhere: the far passes
+        heavy = np.flatnonzero(lens == 300)[:3]                              # rows with more far entries than the cap: kept near
+        cases.append((rows, cols, band, lens, row_of, col, heavy))
+    for rows, cols, band, lens, row_of, col, heavy in cases:
+        extra_rows, extra_cols = [], []
+        for r in heavy:
+            extra_rows.append(np.full(1500, r))
+            extra_cols.append(rng.integers(0, cols, 1500))
+        all_rows = np.concatenate([row_of] + extra_rows)
+        all_cols = np.concatenate([col] + extra_cols)
+        order = np.lexsort((all_cols, all_rows))
+        all_rows, all_cols = all_rows[order], all_cols[order]
+        row_ptr = np.concatenate([[0], np.cumsum(np.bincount(all_rows, minlength=rows))]).astype(np.int32)
+        col_ind = all_cols.astype(np.int32)
+        val = rng.uniform(-1, 1, col_ind.size)
+        x = rng.random(cols)
+        ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+        scale = row_scale(row_ptr, col_ind, val, x)
+        got = {}
+        for near in ("window", "tile"):
+            monkeypatch.setenv("SMVP_BINNED_NEAR", near)
+            A = sm.CsrMatrix(rows, cols, row_ptr, col_ind, val)
+            A.set_kernel(sm.CSR_KERNEL_BINNED, band)
+            name = A.describe()[0]
+            assert ("csr_near_window" in name) == (near == "window"), name
+            buf_x = torch.zeros(cols + 1, dtype=torch.float64, device="cuda")
+            buf_y = torch.full((rows + 1,), float("nan"), dtype=torch.float64, device="cuda")
+            for shift in (0, 1):                                             # 16-byte aligned and not
+                dx, dy = buf_x[shift:shift + cols], buf_y[shift:shift + rows]
+                dx.copy_(dev(torch, x))
+                dy.fill_(float("nan"))
+                A.spmv(dx, dy)
+                torch.cuda.synchronize()
+                y = dy.cpu().numpy()
+                assert_close(y, ref, scale)
+                assert np.array_equal(y, got.setdefault(near, y))            # the same bits, aligned or not, run to run
+            A.close()
+        short = (np.diff(row_ptr) <= 16)
+        assert np.array_equal(got["window"][short], got["tile"][short])     # both sum a short row left to right
+    # more long rows in a block than the window plan takes: it stays on the tile kernel
+    monkeypatch.setenv("SMVP_BINNED_NEAR", "window")
+    rows = 8192
+    lens = np.full(rows, 40)
+    row_ptr, col_ind, val = csr_from_lengths(rng, lens.tolist(), rows)
+    A = sm.CsrMatrix(rows, rows, row_ptr, col_ind, val)
+    A.set_kernel(sm.CSR_KERNEL_BINNED, 4096)
+    assert "csr_stream_owner" in A.describe()[0]
+    x = rng.random(rows)
+    dy = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+    A.spmv(dev(torch, x), dy)
+    torch.cuda.synchronize()
+    assert_close(dy.cpu().numpy(), ob.csr_spmv(row_ptr, col_ind, val, x), row_scale(row_ptr, col_ind, val, x))
+    A.close()
 
 
 @pytest.mark.parametrize("kernel,param", CSR_VARIANTS)
