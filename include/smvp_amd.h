@@ -180,8 +180,12 @@ enum {
                                          (1024 ... 8192) */
     SMVP_CSR_KERNEL_BINNED = 5        /* for matrices with a band around the diagonal plus many entries far from it
                                          (anywhere in an operand much larger than the L2): the entries are kept a second
-                                         time, split by |column - row| > band.  The near part runs on STREAM.  The far
-                                         part never gathers from memory: pass A -- one workgroup per block of 16384
+                                         time, split by |column - row| > band.  The near part is summed out of a row
+                                         block's window of x in LDS (rows of a block of 8192 sorted by length, every
+                                         lane its own row left to right; a row of more than 16 near entries by a
+                                         wavefront) -- or runs on STREAM where that does not suit (band > 4096, or a
+                                         block with more than 1024 such long rows).  The far part never gathers from
+                                         memory either: pass A -- one workgroup per block of 16384
                                          columns, that block of x in LDS -- stores every far product into bins ordered
                                          (row block, column block); pass B -- one workgroup per row block -- sums each
                                          row's far products in ascending column order and adds them to the near sum.
@@ -216,7 +220,7 @@ int smvp_csr_spmv(smvp_csr_t *h, const double *d_x, double *d_y, void *stream);
 int smvp_csr_describe(const smvp_csr_t *h, char *kernel_name, size_t cap, double *alg_bytes);
 /* Kernel launches per product of the current plan: 1, except STREAM_CARRY (2: tiles + carry fix-up), COLSWEEP
  * (its workgroups start in generations that are resident together; config 4 on one GPU: 5) and BINNED (3: near part,
- * far products, far sums). */
+ * far products, far sums; one more where rows that keep their far entries near are summed apart). */
 int smvp_csr_plan_launches(const smvp_csr_t *h, int *launches);
 /* What the current launch plan costs (the reference has no counterpart: its set-up is the three qsorts and the
  * O(nnz * N) renumbering of main-cli.c:340,766-926, untimed): bytes of HBM the format's own arrays take, bytes the plan

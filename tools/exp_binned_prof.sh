@@ -13,7 +13,7 @@ python3 - "$OUT/xb_$TAG.kernel_stats.csv" <<'PY'
 import csv, sys
 for row in csv.DictReader(open(sys.argv[1])):
     n = row["Name"]
-    if "csr_stream_owner" in n or "csr_binned" in n or "csr_colsweep" in n:
+    if "csr_stream_owner" in n or "csr_binned" in n or "csr_colsweep" in n or "csr_near" in n:
         short = n[n.find("csr_"):].split("(")[0]
         print("  %-50s calls %4s  avg %8.1f us  min %8.1f  max %8.1f" % (short[:50], row["Calls"], float(row["AverageNs"]) / 1e3,
                                                                     float(row["MinNs"]) / 1e3, float(row["MaxNs"]) / 1e3))

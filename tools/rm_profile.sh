@@ -19,7 +19,7 @@ r = json.loads(lines[-1])["roofline"] if lines else {"ms_per_product": 0, "frac"
 print("product: %.4f ms  frac %.4f  kernel %s" % (r["ms_per_product"], r["frac"], r["kernel"]))
 for row in csv.DictReader(open(sys.argv[2])):
     n = row["Name"]
-    if "csr_stream_owner" in n or "csr_binned" in n or "csr_colsweep" in n:
+    if "csr_stream_owner" in n or "csr_binned" in n or "csr_colsweep" in n or "csr_near" in n:
         print("  %-60s calls %4s  avg %8.1f us  min %8.1f  max %8.1f" % (n.split("(")[0][-60:], row["Calls"], float(row["AverageNs"]) / 1e3,
                                                                     float(row["MinNs"]) / 1e3, float(row["MaxNs"]) / 1e3))
 PY
