@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--cap", type=int, default=16)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--lib", default="libnear_window_bench.so")
+    ap.add_argument("--balance", action="store_true", help="deal a block's long rows to its wavefronts longest first")
     ap.add_argument("--emulate", action="store_true", help="no GPU: walk the plan the way the kernel does, in Python (small --rows-log2)")
     args = ap.parse_args()
     if not args.emulate:
@@ -57,8 +58,10 @@ def main():
     perm16 = (order - block[order] * RB).astype(np.uint16)
     perm16[~short[order]] = 0xFFFF                              # long rows: written by their wavefront instead
     long_rows = np.nonzero(~short)[0]
+    if args.balance:                                            # inside a block: most steps first
+        long_rows = long_rows[np.lexsort((long_rows, -((lens[long_rows] + 63) // 64), long_rows // RB))]
     l_block = long_rows // RB
-    blk_long_ptr = np.searchsorted(long_rows, np.arange(nblocks + 1) * RB).astype(np.int32)
+    blk_long_ptr = np.searchsorted(l_block, np.arange(nblocks + 1)).astype(np.int32)
     l_q = np.arange(long_rows.size) - blk_long_ptr[l_block]
     l_width = (lens[long_rows] + 63) // 64
     # all slices: short ones, then long rows; a wavefront's run = its short slices, then its long rows
@@ -88,7 +91,9 @@ def main():
     sval[dest] = nv[es]
     sword[dest] = (nci[es] - wbase[nrow[es]]).astype(np.uint16) | VALID
     el = ~es
-    lidx = np.searchsorted(long_rows, nrow[el])                 # which long row
+    which = np.full(rows, -1, dtype=np.int64)
+    which[long_rows] = np.arange(long_rows.size)
+    lidx = which[nrow[el]]                                      # which long row
     dest = (off[nss + lidx] + k[el] // 64) * 64 + k[el] % 64
     sval[dest] = nv[el]
     sword[dest] = (nci[el] - wbase[nrow[el]]).astype(np.uint16) | VALID
@@ -169,6 +174,8 @@ def main():
     got3 = d["y"].cpu().numpy()
     print("near_window, y through LDS: bit-equal to the first form: %s" % bool(np.array_equal(got3, got)))
     print("near_window, y through LDS: %.4f ms" % run(args.steps, 3), flush=True)
+    print("   ... without the window's load (timing only): %.4f ms" % run(args.steps, 4), flush=True)
+    print("   ... without the y phase (timing only): %.4f ms" % run(args.steps, 5), flush=True)
 
     # the tile kernel on the same entries
     A = sm.CsrMatrix(rows, rows, dev(nrp.astype(np.int32)), dev(nci.astype(np.int32)), dev(nv))

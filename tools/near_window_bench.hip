@@ -36,7 +36,8 @@ __device__ inline double wave_sum_fixed(double v)
 
 // variant: 0 = the product; 1 = timing only, y stored in slice order (coalesced) instead of row order; 2 = the product with
 // ordinary instead of non-temporal y stores; 3 = the product, every lane keeps its rows' sums until the block's stream has ended,
-// then the window's LDS becomes the block's y and is stored coalesced
+// then the window's LDS becomes the block's y and is stored coalesced; 4 / 5 = timing only: 3 without the window's load / without
+// the y phase at the block's end
 template <int VARIANT>
 __global__ __launch_bounds__(kThreads) void near_window(const double *__restrict__ x, double *__restrict__ y, int rows, int cols,
                                                        const long long *__restrict__ wave_ptr, const int *__restrict__ wave_n1,
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(kThreads) void near_window(const double *__restrict
     };
     request(0, 0);
     // the window of x, the block's row order, its long rows
+    if constexpr (VARIANT != 4)
     for (int i = 2 * t; i + 1 < wlen; i += 2 * kThreads)
         *reinterpret_cast<double2 *>(&xw[i]) = *reinterpret_cast<const double2 *>(x + wbase + i);
     if ((wlen & 1) && t == 0)
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(kThreads) void near_window(const double *__restrict
         longs[i] = long_row16[lq0 + i];
     __syncthreads();
     // rows of slices without entries
-    if constexpr (VARIANT != 3)
+    if constexpr (VARIANT < 3)
         for (int p = nshort * 64 + t; p < kRB; p += kThreads)
             if (perm[p] != 0xffff)
                 y[R0 + perm[p]] = 0.0;
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(kThreads) void near_window(const double *__restrict
                     if (j0 + u < n1) {
                         const int p = (wave + kWaves * ks) * 64 + lane;
                         const int r = perm[p];
-                        if constexpr (VARIANT == 3) {
+                        if constexpr (VARIANT >= 3) {
 #pragma unroll
                             for (int k = 0; k < kPerWave; ++k)
                                 if (ks == k)
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(kThreads) void near_window(const double *__restrict
                     } else {
                         const int q = wave + kWaves * kl;
                         const double s = wave_sum_fixed(acc);
-                        if constexpr (VARIANT == 3) {
+                        if constexpr (VARIANT >= 3) {
                             if (lane == 0)
                                 lsum[q] = s;  // (the experiment's blocks have at most kLongCap long rows: checked by the driver)
                         } else if (lane == 0)
@@ -141,7 +143,15 @@ __global__ __launch_bounds__(kThreads) void near_window(const double *__restrict
         request(j + 2 * kU, 0);
         batch(j + kU, 1);
     }
-    if constexpr (VARIANT == 3) {
+    if constexpr (VARIANT == 5) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < kPerWave; ++k)
+            s += accs[k];
+        if (s == 123.456)
+            y[R0 + t] = s;
+    }
+    if constexpr (VARIANT == 3 || VARIANT == 4) {
         // everybody has finished with the window: it becomes the block's y, filled in row order and stored coalesced
         __syncthreads();
         double *yb = xw;
@@ -176,12 +186,22 @@ extern "C" float near_window_run(const double *x, double *y, int rows, int cols,
         e = hipFuncSetAttribute((const void *)near_window<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void *)near_window<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)near_window<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)near_window<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
         printf("hipFuncSetAttribute(%zu) failed: %s\n", lds, hipGetErrorString(e));
         return -1.f;
     }
     auto launch = [&] {
-        if (variant == 3)
+        if (variant == 5)
+            hipLaunchKernelGGL(near_window<5>, dim3((unsigned)nblocks), dim3(kThreads), lds, 0, x, y, rows, cols, wave_ptr, wave_n1, wave_n2,
+                               blk_short, perm16, sval, sword, blk_long_ptr, long_row16);
+        else if (variant == 4)
+            hipLaunchKernelGGL(near_window<4>, dim3((unsigned)nblocks), dim3(kThreads), lds, 0, x, y, rows, cols, wave_ptr, wave_n1, wave_n2,
+                               blk_short, perm16, sval, sword, blk_long_ptr, long_row16);
+        else if (variant == 3)
             hipLaunchKernelGGL(near_window<3>, dim3((unsigned)nblocks), dim3(kThreads), lds, 0, x, y, rows, cols, wave_ptr, wave_n1, wave_n2,
                                blk_short, perm16, sval, sword, blk_long_ptr, long_row16);
         else if (variant == 2)

@@ -60,7 +60,8 @@ def main():
     import smvp_toolkit_amd as sm
     import oracle_binding as ob
     csr_variants = [(sm.CSR_KERNEL_STREAM, p) for p in (256, 1024, 2048)] + [(sm.CSR_KERNEL_STREAM_CARRY, p) for p in (1024, 2048)] + \
-                   [(sm.CSR_KERNEL_VECTOR, p) for p in (2, 16, 64)] + [(sm.CSR_KERNEL_COLSWEEP, p) for p in (0, 1024, 8192)]
+                   [(sm.CSR_KERNEL_VECTOR, p) for p in (2, 16, 64)] + [(sm.CSR_KERNEL_COLSWEEP, p) for p in (0, 1024, 8192)] + \
+                   [(sm.CSR_KERNEL_BINNED, p) for p in (0, 1, 7, 100)]
     bad = 0
     for seed in range(a.seeds):
         rows, cols, row_ptr, col_ind, val, x = matrix(seed)
