@@ -17,7 +17,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "smvp-toolkit_amd", "python"))
-RB, BAND, WAVES = 8192, 4096, 16
+RB, BAND, WAVES = 8192, 4096, 16        # (--rb / --waves change the first and the last)
 VALID, END = np.uint16(0x8000), np.uint16(0x4000)
 
 
@@ -27,9 +27,15 @@ def main():
     ap.add_argument("--cap", type=int, default=16)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--lib", default="libnear_window_bench.so")
+    ap.add_argument("--rb", type=int, default=8192)
+    ap.add_argument("--waves", type=int, default=16)
+    ap.add_argument("--xcd", type=int, default=0)
+    ap.add_argument("--longcap", type=int, default=1024)
     ap.add_argument("--balance", action="store_true", help="deal a block's long rows to its wavefronts longest first")
     ap.add_argument("--emulate", action="store_true", help="no GPU: walk the plan the way the kernel does, in Python (small --rows-log2)")
     args = ap.parse_args()
+    global RB, WAVES
+    RB, WAVES = args.rb, args.waves
     if not args.emulate:
         import torch                       # before the library: one HIP runtime in the process
     import smvp_toolkit_amd as sm
@@ -153,7 +159,7 @@ def main():
 
     def run(reps, variant=0):
         return lib.near_window_run(P("x"), P("y"), rows, rows, P("wave_ptr"), P("wave_n1"), P("wave_n2"), P("blk_short"), P("perm16"), P("sval"),
-                                   P("sword"), P("blk_long_ptr"), P("long_row16"), nblocks, reps, variant)
+                                   P("sword"), P("blk_long_ptr"), P("long_row16"), nblocks, reps, variant, args.xcd)
 
     assert run(0) == 0.0
     torch.cuda.synchronize()
@@ -167,7 +173,7 @@ def main():
         ms, nci.size / ms / 1e3, moved / 1e9, moved / ms / 1e6), flush=True)
     print("near_window, y stored in slice order (timing only): %.4f ms" % run(args.steps, 1), flush=True)
     print("near_window, ordinary y stores: %.4f ms" % run(args.steps, 2), flush=True)
-    assert np.diff(blk_long_ptr).max() <= 1024
+    assert np.diff(blk_long_ptr).max() <= args.longcap
     d["y"].fill_(float("nan"))
     run(0, 3)
     torch.cuda.synchronize()

@@ -17,11 +17,20 @@
 
 namespace {
 
-constexpr int kRB = 8192, kBand = 4096, kWin = kRB + 2 * kBand, kThreads = 1024, kWaves = kThreads / 64;
+#ifndef NW_RB
+#define NW_RB 8192
+#endif
+#ifndef NW_THREADS
+#define NW_THREADS 1024
+#endif
+#ifndef NW_LONGCAP
+#define NW_LONGCAP 1024
+#endif
+constexpr int kRB = NW_RB, kBand = 4096, kWin = kRB + 2 * kBand, kThreads = NW_THREADS, kWaves = kThreads / 64;
 #ifndef NW_U
 #define NW_U 8
 #endif
-constexpr int kU = NW_U, kLongCap = 1024, kPerWave = kRB / 64 / kWaves;
+constexpr int kU = NW_U, kLongCap = NW_LONGCAP, kPerWave = kRB / 64 / kWaves;
 constexpr int kValid = 0x8000, kEnd = 0x4000, kColMask = 0x3fff;
 
 typedef double double2v __attribute__((ext_vector_type(2)));
@@ -44,7 +53,7 @@ __global__ __launch_bounds__(kThreads) void near_window(const double *__restrict
                                                        const int *__restrict__ wave_n2, const int *__restrict__ blk_short,
                                                        const unsigned short *__restrict__ perm16, const double *__restrict__ sval,
                                                        const unsigned short *__restrict__ sword, const int *__restrict__ blk_long_ptr,
-                                                       const unsigned short *__restrict__ long_row16)
+                                                       const unsigned short *__restrict__ long_row16, int xcd, int nblocks_arg)
 {
     extern __shared__ double lds[];
     double *xw = lds;
@@ -52,7 +61,13 @@ __global__ __launch_bounds__(kThreads) void near_window(const double *__restrict
     unsigned short *longs = perm + kRB;
     double *lsum = reinterpret_cast<double *>(longs + kLongCap);  // variant 3: the long rows' sums until the window is free
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int b = blockIdx.x;
+    int b = blockIdx.x;
+    if (xcd) {  // XCD i (workgroups i, i + 8, ...) takes the i-th eighth of the row blocks, in order
+        const int per = ((int)gridDim.x + 7) >> 3;
+        b = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+        if (b >= nblocks_arg)
+            return;
+    }
     const long long R0 = (long long)b * kRB;
     const long long wbase = R0 - kBand > 0 ? R0 - kBand : 0;
     const long long wend = R0 + kRB + kBand < (long long)cols ? R0 + kRB + kBand : (long long)cols;
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void near_window(const double *__restrict
 extern "C" float near_window_run(const double *x, double *y, int rows, int cols, const long long *wave_ptr, const int *wave_n1,
                                  const int *wave_n2, const int *blk_short, const unsigned short *perm16, const double *sval,
                                  const unsigned short *sword, const int *blk_long_ptr, const unsigned short *long_row16, int nblocks,
-                                 int reps, int variant)
+                                 int reps, int variant, int xcd)
 {
     const size_t lds = sizeof(double) * kWin + 2 * kRB + 2 * kLongCap + 8 * kLongCap;
     hipError_t e = hipFuncSetAttribute((const void *)near_window<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -196,23 +211,23 @@ extern "C" float near_window_run(const double *x, double *y, int rows, int cols,
     }
     auto launch = [&] {
         if (variant == 5)
-            hipLaunchKernelGGL(near_window<5>, dim3((unsigned)nblocks), dim3(kThreads), lds, 0, x, y, rows, cols, wave_ptr, wave_n1, wave_n2,
-                               blk_short, perm16, sval, sword, blk_long_ptr, long_row16);
+            hipLaunchKernelGGL(near_window<5>, dim3((unsigned)(xcd ? (nblocks + 7) / 8 * 8 : nblocks)), dim3(kThreads), lds, 0, x, y, rows, cols, wave_ptr, wave_n1, wave_n2,
+                               blk_short, perm16, sval, sword, blk_long_ptr, long_row16, xcd, nblocks);
         else if (variant == 4)
-            hipLaunchKernelGGL(near_window<4>, dim3((unsigned)nblocks), dim3(kThreads), lds, 0, x, y, rows, cols, wave_ptr, wave_n1, wave_n2,
-                               blk_short, perm16, sval, sword, blk_long_ptr, long_row16);
+            hipLaunchKernelGGL(near_window<4>, dim3((unsigned)(xcd ? (nblocks + 7) / 8 * 8 : nblocks)), dim3(kThreads), lds, 0, x, y, rows, cols, wave_ptr, wave_n1, wave_n2,
+                               blk_short, perm16, sval, sword, blk_long_ptr, long_row16, xcd, nblocks);
         else if (variant == 3)
-            hipLaunchKernelGGL(near_window<3>, dim3((unsigned)nblocks), dim3(kThreads), lds, 0, x, y, rows, cols, wave_ptr, wave_n1, wave_n2,
-                               blk_short, perm16, sval, sword, blk_long_ptr, long_row16);
+            hipLaunchKernelGGL(near_window<3>, dim3((unsigned)(xcd ? (nblocks + 7) / 8 * 8 : nblocks)), dim3(kThreads), lds, 0, x, y, rows, cols, wave_ptr, wave_n1, wave_n2,
+                               blk_short, perm16, sval, sword, blk_long_ptr, long_row16, xcd, nblocks);
         else if (variant == 2)
-            hipLaunchKernelGGL(near_window<2>, dim3((unsigned)nblocks), dim3(kThreads), lds, 0, x, y, rows, cols, wave_ptr, wave_n1, wave_n2,
-                               blk_short, perm16, sval, sword, blk_long_ptr, long_row16);
+            hipLaunchKernelGGL(near_window<2>, dim3((unsigned)(xcd ? (nblocks + 7) / 8 * 8 : nblocks)), dim3(kThreads), lds, 0, x, y, rows, cols, wave_ptr, wave_n1, wave_n2,
+                               blk_short, perm16, sval, sword, blk_long_ptr, long_row16, xcd, nblocks);
         else if (variant == 1)
-            hipLaunchKernelGGL(near_window<1>, dim3((unsigned)nblocks), dim3(kThreads), lds, 0, x, y, rows, cols, wave_ptr, wave_n1, wave_n2,
-                               blk_short, perm16, sval, sword, blk_long_ptr, long_row16);
+            hipLaunchKernelGGL(near_window<1>, dim3((unsigned)(xcd ? (nblocks + 7) / 8 * 8 : nblocks)), dim3(kThreads), lds, 0, x, y, rows, cols, wave_ptr, wave_n1, wave_n2,
+                               blk_short, perm16, sval, sword, blk_long_ptr, long_row16, xcd, nblocks);
         else
-            hipLaunchKernelGGL(near_window<0>, dim3((unsigned)nblocks), dim3(kThreads), lds, 0, x, y, rows, cols, wave_ptr, wave_n1, wave_n2,
-                               blk_short, perm16, sval, sword, blk_long_ptr, long_row16);
+            hipLaunchKernelGGL(near_window<0>, dim3((unsigned)(xcd ? (nblocks + 7) / 8 * 8 : nblocks)), dim3(kThreads), lds, 0, x, y, rows, cols, wave_ptr, wave_n1, wave_n2,
+                               blk_short, perm16, sval, sword, blk_long_ptr, long_row16, xcd, nblocks);
     };
     launch();
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) {
