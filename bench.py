@@ -225,6 +225,8 @@ def measure_csr(torch, dist, sm, sharding_mod, blk, args, world, local_rank, ran
     pi = A.plan_info()
     plan = {"plan_bytes": pi["plan_bytes"], "matrix_bytes": pi["matrix_bytes"],
             "plan_over_matrix": round(pi["plan_bytes"] / max(1.0, pi["matrix_bytes"]), 3), "plan_build_ms": round(pi["build_ms"], 1)}
+    if fmt == "tjds":
+        plan["value_cache"] = _value_cache(A, blk["nnz"])
 
     x_host = np.ones(blk["cols_total"]) if args.x == "ones" else np.random.default_rng(67890).random(blk["cols_total"])
     d_x = torch.from_numpy(x_host).cuda()
@@ -652,9 +654,15 @@ def measure_pwt_tiled(torch, dist, sm, sharding_mod, local_rank, rank, steps):
                    "frac_of_hbm_peak": round(tbytes / tms * 1e-6 / HBM_PEAK_GBS, 4), "equals_csr_bit_for_bit": True,
                    "plan": {"plan_bytes": tpi["plan_bytes"], "matrix_bytes": tpi["matrix_bytes"],
                             "plan_over_matrix": round(tpi["plan_bytes"] / max(1.0, tpi["matrix_bytes"]), 3),
-                            "plan_build_ms": round(tpi["build_ms"], 1)}}
+                            "plan_build_ms": round(tpi["build_ms"], 1), "value_cache": _value_cache(T, nnz)}}
     T.close()
     return out
+
+
+def _value_cache(T, nnz):
+    """The TJDS product's value cache: val lines shared by `min_tiles` tiles or more keep a tile-ordered second copy."""
+    min_tiles, cached = T.get_value_cache()
+    return {"min_tiles": min_tiles, "cached_share": round(cached / max(1, nnz), 4)}
 
 
 def recorded_traffic(workload, kernel, alg_bytes):
@@ -972,7 +980,7 @@ def main():
                              "max_normwise_diff_vs_csr": terr, "steps": tsteps,
                              "plan": {"plan_bytes": tpi["plan_bytes"], "matrix_bytes": tpi["matrix_bytes"],
                                       "plan_over_matrix": round(tpi["plan_bytes"] / max(1.0, tpi["matrix_bytes"]), 3),
-                                      "plan_build_ms": round(tpi["build_ms"], 1)},
+                                      "plan_build_ms": round(tpi["build_ms"], 1), "value_cache": _value_cache(T, blk["nnz"])},
                              "convert_device_ms": round(t_conv * 1e3, 1),
                              "traffic_bytes_per_product": trec[0] if trec else None,
                              "traffic_source": ("profiles/" + trec[1]) if trec else None,

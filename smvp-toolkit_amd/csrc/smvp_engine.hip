@@ -126,7 +126,7 @@ struct smvp_csr {
     // A line split over two or three tiles is the edge between neighbouring tiles (they run together on one XCD: an L2
     // hit); from four on its entries belong to unrelated rows.  Measured on memplus x944 (profiles/r03_tjds_forms_measured.txt):
     // none 0.555 ms / 3.66 GB moved, >= 8 tiles 0.461 / 2.92 (20 % of the values cached), >= 4 tiles 0.444 / 2.73 (35 %).
-    int cache_min_tiles = 4, cached_total = 0, ovf_total = 0;
+    int cache_min_tiles = 2, cached_total = 0, ovf_total = 0;  // 2: every val line that is not one tile's alone (measured, r04)
     int *d_cache_ptr = nullptr;
     double *d_val_cache = nullptr;
     // TjdsH: the 16-bit second word of every entry, the tiles' runs (start_pos of each run's diagonal), each group of 32's run
