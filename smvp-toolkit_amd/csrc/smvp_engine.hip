@@ -159,6 +159,10 @@ struct smvp_csr {
     // the tile kernel through the nested handle `near`; the far part as the two streams and the bins of smvp_binned.hip
     smvp::BinnedPlan bin;
     smvp_csr *near = nullptr;
+    // BINNED with the window plan: pass A (it needs x only) goes onto a stream of its own, ahead of the near part, and
+    // the near part's workgroups take the CUs as pass A's last ones leave them
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     double far_share = -2.0;   // share of entries with |column - row| > kBinNearBand; -2: not measured yet
     bool plain_only = false;   // a nested handle: AUTO stays on the tile kernels
     int sweep_g = 0;           // COLSWEEP: chunks in flight per wavefront (fixed when the plan is built)
@@ -172,6 +176,14 @@ void free_binned(smvp_csr *h)
     smvp_csr_destroy(h->near);
     h->near = nullptr;
     smvp::free_binned_plan(&h->bin);
+    if (h->side)
+        (void)hipStreamDestroy(h->side);
+    if (h->ev_fork)
+        (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join)
+        (void)hipEventDestroy(h->ev_join);
+    h->side = nullptr;
+    h->ev_fork = h->ev_join = nullptr;
 }
 
 void free_sweep_plan(smvp_csr *h)
@@ -643,8 +655,15 @@ static int build_binned(smvp_csr *h, int band)
         window = strcmp(e, "tile") != 0;
     if (int rc = smvp::build_binned_plan(h->d_row_ptr, h->d_col_ind, h->d_val, h->rows, h->cols, h->nnz, band, window, &h->bin, nullptr))
         return rc;
-    if (h->bin.nw.on)
+    if (h->bin.nw.on) {
+        const char *e = getenv("SMVP_BINNED_OVERLAP");  // development switch (plan time): 0 = pass A behind the near part, one stream
+        if ((!e || atoi(e) != 0) && h->bin.nf > 0) {
+            HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        }
         return SMVP_OK;
+    }
     return csr_create_impl(&h->near, h->device, h->rows, h->cols, h->bin.nnz_near, h->bin.near_ptr, h->bin.near_col, h->bin.near_val,
                            SMVP_MEM_DEVICE, nullptr, smvp::kFlavorCsr, nullptr, true);
 }
@@ -733,11 +752,32 @@ static int csr_spmv_impl(smvp_csr_t *h, const double *d_x, double *d_y, void *st
     hipError_t e;
     if (h->kernel == SMVP_CSR_KERNEL_BINNED) {
         // the near part writes every row of y; pass A puts the far products into the bins; pass B adds each row's far sum.
-        // (Pass A needs x only and was tried beside the near product, twice.  On a stream of its own its one workgroup per
+        // (With the near part on the TILE kernel, pass A was tried beside it twice.  On a stream of its own its one workgroup per
         // CU -- 132 KB of LDS -- only got onto a CU once the tile kernel's six had drained: one after the other anyway,
         // 0.777 against 0.757 ms.  As one persistent workgroup per CU enqueued AHEAD of the near product the two did share
         // the CUs -- and pass A then took 264 instead of 238 us while the near product finished 241 us after it instead of
         // 303: 0.7485 against 0.7540 ms.  What one gains the other loses: profiles/r04_binned_measured.txt.)
+        if (h->bin.nw.on && h->side) {
+            // The window plan's near part and pass A are both one-workgroup-per-CU kernels (148 / 132 KB of LDS): enqueued
+            // side by side -- pass A first, on a stream of its own: it needs x only -- their workgroups share the chip one
+            // CU at a time, the near part's take the CUs that pass A's last workgroups leave, and a kernel that mostly
+            // reads runs beside one that writes 40 % of its bytes: 0.683-0.697 -> 0.651-0.669 ms on the random model
+            // (profiles/r04_binned_measured.txt, section 12; the near part first: 0.668-0.670).  Pass B waits for both.
+            HIP_TRY(hipEventRecord(h->ev_fork, st));
+            HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+            e = smvp::launch_binned_products(h->bin, d_x, h->side);
+            if (e != hipSuccess)
+                return smvp::fail(SMVP_ERR_HIP, "CSR launch failed: %s", hipGetErrorString(e));
+            HIP_TRY(hipEventRecord(h->ev_join, h->side));
+            e = smvp::launch_near_window(h->bin.nw, d_x, d_y, st);
+            if (e != hipSuccess)
+                return smvp::fail(SMVP_ERR_HIP, "CSR launch failed: %s", hipGetErrorString(e));
+            HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
+            e = smvp::launch_binned_sums(h->bin, d_y, st);
+            if (e != hipSuccess)
+                return smvp::fail(SMVP_ERR_HIP, "CSR launch failed: %s", hipGetErrorString(e));
+            return SMVP_OK;
+        }
         if (h->bin.nw.on) {
             e = smvp::launch_near_window(h->bin.nw, d_x, d_y, st);
             if (e != hipSuccess)

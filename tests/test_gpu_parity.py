@@ -363,7 +363,8 @@ def test_binned_near_engines(torch, monkeypatch):
     row blocks with a ragged last one, rows of 0 ... 16 (lanes of a slice), 17 ... 300 (slices of their own) entries, empty
     stretches, columns at the window's edges, a rectangular matrix with fewer columns than rows, rows that keep their far
     entries near (outside the window), unaligned operands, more long rows in a block than the window plan takes (it then
-    stays on the tile kernel); the window plan's bits do not change from run to run."""
+    stays on the tile kernel); the window plan's bits do not change from run to run, nor with pass A running beside the near
+    part (a stream of its own, the default) or behind it."""
     rng = np.random.default_rng(77)
     cases = []
     for rows, cols, band in ((20_000, 20_000, 0), (8192 * 2 + 77, 30_000, 4096), (9_000, 2_500, 100), (70_000, 70_000, 1)):
@@ -395,12 +396,13 @@ def test_binned_near_engines(torch, monkeypatch):
         ref = ob.csr_spmv(row_ptr, col_ind, val, x)
         scale = row_scale(row_ptr, col_ind, val, x)
         got = {}
-        for near in ("window", "tile"):
-            monkeypatch.setenv("SMVP_BINNED_NEAR", near)
+        for near in ("window", "window, one stream", "tile"):
+            monkeypatch.setenv("SMVP_BINNED_NEAR", near.split(",")[0])
+            monkeypatch.setenv("SMVP_BINNED_OVERLAP", "0" if "one stream" in near else "1")   # pass A beside the near part, or behind it
             A = sm.CsrMatrix(rows, cols, row_ptr, col_ind, val)
             A.set_kernel(sm.CSR_KERNEL_BINNED, band)
             name = A.describe()[0]
-            assert ("csr_near_window" in name) == (near == "window"), name
+            assert ("csr_near_window" in name) == near.startswith("window"), name
             buf_x = torch.zeros(cols + 1, dtype=torch.float64, device="cuda")
             buf_y = torch.full((rows + 1,), float("nan"), dtype=torch.float64, device="cuda")
             for shift in (0, 1):                                             # 16-byte aligned and not
@@ -415,6 +417,7 @@ def test_binned_near_engines(torch, monkeypatch):
             A.close()
         short = (np.diff(row_ptr) <= 16)
         assert np.array_equal(got["window"][short], got["tile"][short])     # both sum a short row left to right
+        assert np.array_equal(got["window"], got["window, one stream"])     # the same kernels, side by side or one after the other
     # more long rows in a block than the window plan takes: it stays on the tile kernel
     monkeypatch.setenv("SMVP_BINNED_NEAR", "window")
     rows = 8192
