@@ -189,7 +189,10 @@ enum {
                                          columns, that block of x in LDS -- stores every far product into bins ordered
                                          (row block, column block); pass B -- one workgroup per row block -- sums each
                                          row's far products in ascending column order and adds them to the near sum.
-                                         No atomics.  param: the band (0 = 4096) */
+                                         No atomics.  Pass A runs beside the near part on a stream the handle owns
+                                         (ordered against the caller's stream by events); a handle is therefore used by
+                                         one stream at a time, like every plan that keeps buffers.  param: the band
+                                         (0 = 4096) */
 };
 enum {
     SMVP_MEM_HOST = 0,  /* arrays are host memory: copied to the device */
