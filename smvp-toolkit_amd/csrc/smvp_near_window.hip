@@ -67,7 +67,7 @@ __device__ __forceinline__ double wave_sum_fixed(double v)
 }
 
 __global__ __launch_bounds__(kThreads) void csr_near_window(const double *__restrict__ x, double *__restrict__ y, int rows, int cols,
-                                                           const int *__restrict__ wave_ptr, const int *__restrict__ wave_n1,
+                                                           int nblocks, const int *__restrict__ wave_ptr, const int *__restrict__ wave_n1,
                                                            const int *__restrict__ wave_n2, const unsigned short *__restrict__ perm16,
                                                            const double *__restrict__ sval, const unsigned short *__restrict__ sword,
                                                            const int *__restrict__ blk_long_ptr,
@@ -79,7 +79,12 @@ __global__ __launch_bounds__(kThreads) void csr_near_window(const double *__rest
     unsigned short *longs = perm + kRB;
     double *lsum = reinterpret_cast<double *>(longs + kNwLongCap);  // the long rows' sums until the window is free
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int b = blockIdx.x;
+    // Workgroups go to the XCDs round robin: XCD i (workgroups i, i + 8, ...) takes the i-th eighth of the row blocks, in
+    // order, so that the half windows neighbouring blocks share meet in one L2 (-0.8 % on the product; alone: nothing)
+    const int per_xcd = (nblocks + 7) >> 3;
+    const int b = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (b >= nblocks)
+        return;
     const long long R0 = (long long)b * kRB;
     const long long wbase = R0 - kBand > 0 ? R0 - kBand : 0;
     const long long wend = R0 + kRB + kBand < (long long)cols ? R0 + kRB + kBand : (long long)cols;
@@ -559,7 +564,8 @@ hipError_t launch_near_window(const NearWindow &p, const double *x, double *y, h
         if (dev < 64)
             asked.fetch_or(1ull << dev);
     }
-    hipLaunchKernelGGL(csr_near_window, dim3((unsigned)p.nblocks), dim3(kThreads), kLds, stream, x, y, p.rows, p.cols, p.wave_ptr,
+    hipLaunchKernelGGL(csr_near_window, dim3((unsigned)((p.nblocks + 7) / 8 * 8)), dim3(kThreads), kLds, stream, x, y, p.rows, p.cols,
+                       p.nblocks, p.wave_ptr,
                        p.wave_n1, p.wave_n2, p.perm16, p.sval, p.sword, p.blk_long_ptr, p.long_row16);
     if (p.n_out > 0)
         hipLaunchKernelGGL(csr_near_outside_rows, dim3((unsigned)((p.n_out + 3) / 4)), dim3(256), 0, stream, p.n_out, p.out_row, p.out_ptr,
