@@ -50,7 +50,10 @@ namespace smvp {
 namespace {
 
 constexpr int kRB = kNwRowBlock, kBand = kNwBand, kWin = kRB + 2 * kBand, kThreads = 1024, kWaves = kThreads / 64;
-constexpr int kSlices = kRB / 64, kPerWave = kSlices / kWaves, kU = 8;
+#ifndef SMVP_NW_U
+#define SMVP_NW_U 8
+#endif
+constexpr int kSlices = kRB / 64, kPerWave = kSlices / kWaves, kU = SMVP_NW_U;  // steps per batch (4, 12, 16 measured: no better)
 constexpr int kValid = 0x8000, kEnd = 0x4000, kColMask = 0x3fff;
 constexpr size_t kLds = sizeof(double) * kWin + 2 * kRB + 2 * kNwLongCap + 8 * kNwLongCap;
 static_assert(kWin <= kColMask + 1, "a window column fits 14 bits");

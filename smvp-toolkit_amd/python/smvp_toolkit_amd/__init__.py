@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))          # smvp-toolkit_amd/
 REPO_ROOT = os.path.dirname(PKG_ROOT)
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libsmvp_amd.so")
+LIB_PATH = os.environ.get("SMVP_LIB_PATH") or os.path.join(PKG_ROOT, "lib", "libsmvp_amd.so")   # (the override: A/B of two builds in one gpurun call)
 CLI_PATH = os.path.join(PKG_ROOT, "bin", "smvp-toolkit-cli")
 
 OK = 0
