@@ -6,7 +6,8 @@
 // 1.8 GB of matrix: the product runs at the chip's L2-miss gather rate, 21 % of HBM peak).  Here the entries are split
 // at plan time by |column - row| > band:
 //
-//   near   its own CSR arrays, run by the tile kernel (csr_stream_owner) as they are: its gathers stay inside the L2.
+//   near   summed out of a row block's window of x in LDS (K6, smvp_near_window.hip: built from the near CSR arrays, which are
+//          then released) -- or, where that plan does not suit, its own CSR arrays on the tile kernel (csr_stream_owner).
 //   far    two passes that never gather from memory:
 //     pass A  (csr_binned_far_products) one workgroup per COLUMN BLOCK of 16384 columns: the block of x is loaded into
 //             LDS once (128 KB), the block's far entries are streamed -- 8-byte value + 16-bit word (local column | first-
@@ -25,7 +26,8 @@
 //
 // Every x line is read once per product instead of once per far entry; per far entry the product moves 10 B (stream A)
 // + 8 B (bin written) + 8 B + 2 B (bin and word read) = 28 B instead of 128 + 12.  No atomics anywhere: the result is the
-// same from run to run, bit for bit.  A row's sum is (near part, tile-kernel order) + (far part, left to right).
+// same from run to run, bit for bit.  A row's sum is (near part, left to right for a row of at most 16 near entries) + (far
+// part, left to right).  Pass A needs x only: with K6 it runs beside the near part on a stream of its own (engine).
 //
 // The plan -- near arrays, both streams, the bins -- is built on the device (rocPRIM sorts and scans: set-up work).
 #include "smvp_common.h"

@@ -155,8 +155,9 @@ struct smvp_csr {
     int *d_sweep_col = nullptr;
     double *d_sweep_val = nullptr;
     unsigned short *d_sweep_row = nullptr;
-    // BINNED: the entries a second time, split by |column - row| > band: the near part as CSR arrays of its own, run by
-    // the tile kernel through the nested handle `near`; the far part as the two streams and the bins of smvp_binned.hip
+    // BINNED: the entries a second time, split by |column - row| > band: the near part as the window plan bin.nw (K6) or,
+    // where that does not suit, as CSR arrays of its own run by the tile kernel through the nested handle `near`; the far
+    // part as the two streams and the bins of smvp_binned.hip
     smvp::BinnedPlan bin;
     smvp_csr *near = nullptr;
     // BINNED with the window plan: pass A (it needs x only) goes onto a stream of its own, ahead of the near part, and
