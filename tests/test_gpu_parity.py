@@ -434,6 +434,35 @@ def test_binned_near_engines(torch, monkeypatch):
     A.close()
 
 
+def test_binned_products_in_stream_order(torch):
+    """The binned plan runs pass A on a stream of its own beside the near part.  Towards the caller it must still behave like
+    one stream: x written just before a product (by a copy on the caller's stream) is the x every kernel of that product reads,
+    and y is complete for whatever the caller enqueues next -- a power iteration on a side stream of the caller's, five
+    products with the operand rewritten from y in between, against the same iteration on the host."""
+    rows = 1 << 20
+    row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_MEMPLUS_SHAPED, 4242, rows, rows)
+    A = sm.CsrMatrix(rows, rows, row_ptr, col_ind, val)
+    A.set_kernel(sm.CSR_KERNEL_BINNED, 0)
+    assert "csr_near_window" in A.describe()[0]
+    x = sm.vector_random(rows)
+    want = x.copy()
+    for _ in range(5):
+        want = ob.csr_spmv(row_ptr, col_ind, val, want)
+        want /= np.abs(want).max()
+    s = torch.cuda.Stream()
+    dx, dy = dev(torch, x), torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        for _ in range(5):
+            A.spmv(dx, dy, stream=s)
+            dx.copy_(dy / dy.abs().max())          # enqueued on s right behind the product; the next product reads it
+            dy.fill_(float("nan"))                 # ... and nothing of the product may still be writing y
+    s.synchronize()
+    got = dx.cpu().numpy()
+    assert np.all(np.isfinite(got)) and np.max(np.abs(got - want)) < 1e-9
+    A.close()
+
+
 @pytest.mark.parametrize("kernel,param", CSR_VARIANTS)
 def test_csr_matrix_without_rows(torch, kernel, param):
     """rows == 0 (the sharded layer makes such handles for empty chunks): every family plans and launches nothing."""
