@@ -98,6 +98,14 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+# Untimed products in front of a leg's timed region.  A leg follows seconds of host work (building and checking its matrix),
+# and the first milliseconds of device work after such a pause run slower than the steady state (measured: the random-model
+# leg read 0.677 ms with 3 warm-up products and 50 timed ones, 0.650 ms with 20 and 200 in the same process on the same box,
+# profiles/r04_binned_measured.txt section 13): every leg warms up for about 10-20 ms.
+WARM_SHORT = 20   # products of < 1 ms
+WARM_LONG = 8     # products of a few ms (config 4)
+
+
 def timed_region(torch, dist, world, steps, body):
     """barrier + sync, `steps` x body(), sync + barrier -> (wall seconds, HIP-event ms), both MAX over ranks."""
     if world > 1:
@@ -347,7 +355,7 @@ def measure_config4(torch, dist, sm, sharding_mod, args, world, local_rank, rank
             r0, r1 = ex.ranges[c]
             if r1 > r0:
                 mats[c].spmv(d_x, out, stream=stream)
-        for _ in range(2):
+        for _ in range(WARM_LONG):
             ex.step(product, overlap=False, gather=False)
         _, ev = timed_region(torch, dist, world, n, lambda: ex.step(product, overlap=False, gather=False))
         return ev / n
@@ -410,7 +418,7 @@ def measure_config4(torch, dist, sm, sharding_mod, args, world, local_rank, rank
             raise SystemExit("config 4: all-gathered y differs between ranks")
 
     def run(overlap, do_gather):
-        for _ in range(2):
+        for _ in range(WARM_LONG):
             ex.step(product, overlap=overlap, gather=do_gather)
         wall, ev = timed_region(torch, dist, world, steps, lambda: ex.step(product, overlap=overlap, gather=do_gather))
         return wall / steps * 1e3, ev / steps
@@ -528,7 +536,7 @@ def measure_config4(torch, dist, sm, sharding_mod, args, world, local_rank, rank
                     for A, buf, (r0, r1) in zip(m8, bufs, ranges):
                         if r1 > r0:
                             A.spmv(d_x, buf, stream=stream)
-                for _ in range(3):
+                for _ in range(WARM_LONG):
                     eighth()
                 _, ev = timed_region(torch, dist, 1, steps, eighth)
                 product_ms[c] = ev / steps
@@ -621,7 +629,7 @@ def measure_pwt_tiled(torch, dist, sm, sharding_mod, local_rank, rank, steps):
     if not (np.array_equal(y[0], np.diff(rp).astype(np.float64)) and np.array_equal(y, np.tile(y[0], (copies, 1)))
             and all(("%g" % a) == b for a, b in zip(y[0], want))):
         raise SystemExit("pwt x%d: y is not tile(y_pwt of the committed report)" % copies)
-    for _ in range(3):
+    for _ in range(WARM_SHORT):
         A.spmv(d_x, d_y, stream=stream)
     _, ms = timed_region(torch, dist, 1, steps, lambda: A.spmv(d_x, d_y, stream=stream))
     ms /= steps
@@ -648,6 +656,8 @@ def measure_pwt_tiled(torch, dist, sm, sharding_mod, local_rank, rank, steps):
         raise SystemExit("pwt x%d: TJDS differs from CSR" % copies)
     tname, tbytes = T.describe()
     tpi = T.plan_info()
+    for _ in range(WARM_SHORT):
+        T.spmv(d_yt, stream=stream)
     _, tms = timed_region(torch, dist, 1, steps, lambda: T.spmv(d_yt, stream=stream))
     tms /= steps
     out["tjds"] = {"kernel": tname, "ms_per_step": round(tms, 5), "alg_bytes_per_product": tbytes, "GFLOPs": round(2.0 * nnz / tms * 1e-6, 1),
@@ -967,7 +977,7 @@ def main():
             if terr > TOL:
                 raise RuntimeError("TJDS differs from CSR: %g" % terr)
             tsteps = max(5, args.steps // 4)
-            for _ in range(min(args.warmup, 5)):
+            for _ in range(min(args.warmup, WARM_SHORT)):
                 tjds_step()
             _, t_ms = timed_region(torch, dist, 1, tsteps, tjds_step)
             t_ms /= tsteps
@@ -1181,7 +1191,8 @@ def main():
     if args.workload == "memplus_tiled" and not args.no_random_model and world == 1:
         try:
             blk2 = build_block(sm, sharding, "memplus_shaped", args, rank, world)
-            r2 = measure_csr(torch, dist, sm, sharding, blk2, args, world, local_rank, rank, max(10, args.steps // 4), 3, False)
+            r2 = measure_csr(torch, dist, sm, sharding, blk2, args, world, local_rank, rank, max(10, args.steps // 2),
+                             min(args.warmup, WARM_SHORT), False)
             rl = roofline_of(r2)
             far = float((np.abs(np.repeat(np.arange(blk2["rows"]), np.diff(blk2["row_ptr"])) - blk2["col_ind"]) > 4096).mean())
             extra["survey_random_model"] = {
@@ -1211,7 +1222,7 @@ def main():
             del y_first
             if auto_kernel[0] != sm.CSR_KERNEL_STREAM:
                 A2.set_kernel(sm.CSR_KERNEL_STREAM, 0)
-                for _ in range(3):
+                for _ in range(WARM_LONG):
                     A2.spmv(r2["d_x"], r2["d_y"], stream=st2)
                 tsteps = max(5, args.steps // 8)
                 _, t_ms = timed_region(torch, dist, 1, tsteps, lambda: A2.spmv(r2["d_x"], r2["d_y"], stream=st2))
