@@ -26,11 +26,22 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--kernel", default="binned", choices=["binned", "auto", "stream", "colsweep"])
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--churn", type=int, default=0, help="allocate and free this many odd-sized device buffers first (memory placement experiment)")
     args = ap.parse_args()
     import torch
     import smvp_toolkit_amd as sm
 
     rows = 1 << args.rows_log2
+    if args.churn:
+        rng = np.random.default_rng(1)
+        held = []
+        for i in range(args.churn):
+            held.append(torch.empty(int(rng.integers(1 << 20, 1 << 29)), dtype=torch.uint8, device="cuda"))
+            if len(held) > 24:
+                del held[int(rng.integers(0, len(held)))]
+        keep = held[::3]                 # every third stays: what comes next is allocated around them
+        del held
+        torch.cuda.empty_cache()
     if args.kind == "memplus":
         rp, ci, v = sm.synth_csr(sm.SYNTH_MEMPLUS_SHAPED, 12345, rows, rows, threads=16)
     else:
