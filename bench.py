@@ -86,6 +86,9 @@ def parse():
     ap.add_argument("--c-layer-child", type=int, default=0, help=argparse.SUPPRESS)   # child process: the C layer alone on this many GPUs
     ap.add_argument("--c-layer-budget", type=float, default=240.0,
                     help="N > 1: wall-clock seconds the C-layer leg (a child process of rank 0) may take before it is given up")
+    ap.add_argument("--launch-budget", type=float, default=1500.0,
+                    help="--gpus N > 1 started WITHOUT a launcher: wall-clock seconds the N rank processes this script starts "
+                         "for itself may take before they are ended")
     ap.add_argument("--cpu-iters", type=int, default=0, help="0 = sized for about 15 s")
     ap.add_argument("--no-allgather", action="store_true", help="N > 1: time the local products only")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
@@ -216,7 +219,7 @@ def measure_csr(torch, dist, sm, sharding_mod, blk, args, world, local_rank, ran
         d_row_ptr = torch.from_numpy(blk["row_ptr"]).cuda()
         d_col_ind = torch.from_numpy(blk["col_ind"]).cuda()
         d_val = torch.from_numpy(blk["val"]).cuda()
-        A = sm.CsrMatrix(blk["rows"], blk["cols_total"], d_row_ptr, d_col_ind, d_val, device=local_rank)
+        A = sm.CsrMatrix(blk["rows"], blk["cols_total"], d_row_ptr, d_col_ind, d_val, device=local_rank, first_row=blk["r0"])
         if args.kernel != "auto" or args.kernel_param:
             A.set_kernel({"auto": 0, "vector": 1, "stream": 2, "stream-carry": 3, "colsweep": 4, "binned": 5}[args.kernel], args.kernel_param)
     else:   # TJDS of this rank's row block, built on the GPU from the block's entries
@@ -320,7 +323,7 @@ def _config4_block(torch, sm, rows, ranges, local_rank, threads):
     for r0, r1 in ranges:
         rp, ci, v = sm.synth_csr(sm.SYNTH_UNIFORM, 2024, rows, rows, 32, r0, r1, threads=threads)
         A = sm.CsrMatrix(r1 - r0, rows, torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(v).cuda(),
-                         device=local_rank)
+                         device=local_rank, first_row=r0)
         n = int(rp[-1])
         nnz_local += n
         alg_local += 12.0 * n + 4.0 * (r1 - r0 + 1) + 8.0 * (r1 - r0)     # x is counted once per rank, by the caller, not once per chunk
@@ -766,13 +769,13 @@ def measure_c_layer(sm, rows, ngpus, steps, rank):
     out = {"workload": "uniform 32 entries/row rows=%d seed=2024 (BASELINE config 4)" % rows, "n_gpus": ngpus, "nnz": nnz, "steps": steps,
            "what": "smvp_sharded_spmv (C ABI, one process drives all GPUs; row blocks balanced by entries, each cut into row "
                    "chunks; RCCL all-gather of y per chunk)"}
-    # fewer GPUs than ranks (a rehearsal on one GPU): the ranks share them and the y blocks travel by device-to-device copies
+    # fewer GPUs than ranks (a rehearsal on one GPU): the ranks share them and the y blocks travel by peer pushes.  Otherwise
+    # SMVP_EXCHANGE_AUTO: RCCL's all-gather, peer copies and the push kernel each move one product's y when the handle is
+    # created, the fastest is kept -- and this leg reports all of them, and the overlapped step under each
     virtual = ngpus > sm.device_count()
-    out["exchange"] = "device-to-device copies between virtual ranks (rehearsal: %d ranks on %d GPU(s))" % (ngpus, sm.device_count()) \
-        if virtual else "RCCL ncclAllGather, one communicator rank per GPU"
     for chunks in (1, 4):
         S = sm.ShardedMatrix("csr", ngpus, rows, rows, csr=(rp, ci, v), chunks=chunks,
-                             exchange=sm.EXCHANGE_COPIES if virtual else sm.EXCHANGE_RCCL)
+                             exchange=sm.EXCHANGE_DIRECT if virtual else sm.EXCHANGE_AUTO)
         S.set_x(None)
         S.spmv(allgather=sm.GATHER_OVERLAPPED)
         S.synchronize()
@@ -783,7 +786,29 @@ def measure_c_layer(sm, rows, ngpus, steps, rank):
         S.synchronize()
         if not np.array_equal(S.get_y(0, gathered=True), ys[0]):
             raise SystemExit("C layer: GATHER_AFTER and GATHER_OVERLAPPED differ")
-        form = {}
+        info = S.probe_exchange(5)          # y_local now holds a real product's chunks
+        chosen = info["active"]
+        form = {"exchange_ms": {k: round(v_, 4) for k, v_ in info["ms"].items()}, "exchange_chosen": info["active_name"]}
+        if chunks == 1:
+            out["exchange"] = ("peer pushes between virtual ranks (rehearsal: %d ranks on %d GPU(s))" % (ngpus, sm.device_count())
+                               if virtual else "AUTO -> %s (RCCL ncclAllGather / peer hipMemcpyAsync / push kernel, timed at creation)" % info["active_name"])
+            out["exchange_chosen"], out["rccl_ranks"] = info["active_name"], info["rccl_ranks"]
+            for k, v_ in info["ms"].items():
+                out["exchange_%s_ms" % k] = round(v_, 4)
+        by_exchange = {}
+        for ex in info["available"]:
+            S.set_exchange(ex)
+            S.spmv(allgather=sm.GATHER_OVERLAPPED)
+            S.synchronize()
+            if not np.array_equal(S.get_y(ngpus - 1, gathered=True), ys[0]):
+                raise SystemExit("C layer: exchange %s gives other bits" % sm.EXCHANGE_NAMES[ex])
+            ev = []
+            for _ in range(steps):
+                S.spmv(allgather=sm.GATHER_OVERLAPPED, timed=True)
+                ev.append(S.synchronize())
+            by_exchange[sm.EXCHANGE_NAMES[ex]] = round(float(np.mean(ev)), 4)
+        form["overlapped_ms_by_exchange"] = by_exchange
+        S.set_exchange(chosen)
         for label, mode in (("products_only", sm.GATHER_NONE), ("products_then_allgather", sm.GATHER_AFTER),
                             ("overlapped", sm.GATHER_OVERLAPPED)):
             for _ in range(2):
@@ -842,6 +867,146 @@ def c_layer_in_child(args, ngpus, steps, rank):
     return res
 
 
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no RANK / WORLD_SIZE in the environment -- the way
+    the driver starts the scaling runs): this process becomes the launcher.  BEFORE importing torch or touching HIP in
+    any way it starts the N ranks as child processes of its own -- this same script with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT set, each the leader of its own process group -- relays rank 0's stdout (the one
+    JSON line), lets every rank's stderr through, waits under a wall-clock budget and returns the worst exit code.  Never
+    os.exec*.  When a rank dies the others are given a short grace (they would wait for it in a collective for ever) and are
+    then ended -- by the exact process groups started here.  The torch.distributed.run path stays as it was."""
+    import signal
+    import socket
+    import subprocess
+
+    n = args.gpus
+    with socket.socket() as s:      # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC")}
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), SMVP_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    log(0, "--gpus %d without a launcher: starting %d rank processes (rendezvous 127.0.0.1:%d, budget %.0f s)" % (n, n, port, args.launch_budget))
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0", ROLE_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True if r == 0 else None,
+                                      start_new_session=True))
+
+    def end(p):
+        if p.poll() is None:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)     # the process group this rank was started as (its own children too)
+            except Exception:
+                try:
+                    p.kill()
+                except Exception:
+                    pass
+
+    import threading
+
+    lines = []
+
+    def relay():        # rank 0's stdout, line by line as it comes
+        for l in procs[0].stdout:
+            lines.append(l)
+            sys.stdout.write(l)
+            sys.stdout.flush()
+
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    deadline = time.time() + args.launch_budget
+    grace = None
+    why = ""
+    while any(p.poll() is None for p in procs):
+        now = time.time()
+        failed = [i for i, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if failed and grace is None:
+            grace = now + 30.0
+            why = "rank %d exited with %s" % (failed[0], procs[failed[0]].returncode)
+        if now > deadline or (grace is not None and now > grace):
+            why = why or "the ranks did not finish within --launch-budget %.0f s" % args.launch_budget
+            for p in procs:
+                end(p)
+            break
+        time.sleep(0.1)
+    for p in procs:
+        try:
+            p.wait(timeout=15)
+        except Exception:
+            end(p)
+    t.join(timeout=10)
+    codes = [p.returncode if p.returncode is not None else -9 for p in procs]
+    rc = 0 if all(c == 0 for c in codes) else next((c for c in codes if c > 0), 1)
+    if rc == 0 and not any(l.startswith("{") for l in lines):
+        why, rc = "rank 0 printed no JSON line", 1
+    if rc:
+        log(0, "self-launched run failed (%s); exit codes by rank: %s" % (why or "non-zero exit", codes))
+    return rc
+
+
+def flat_keys(roof, others, extra, world, dist_info):
+    """The figures a scaling record needs as FLAT SCALARS inside `roofline`: the driver's parse keeps the scalar keys of
+    `roofline` / `cpu_baseline` / `config` (strings cut at 128 characters) and drops every nested object -- `roofline.others`,
+    `plan`, `setup`, `extra` survive only as fragments of a truncated stdout tail (BENCH_r02 ... r04).  Same keys at every N;
+    a leg that did not run leaves its keys out.  `others` stays on the line for a human reader."""
+    def put(key, val, nd=4):
+        if val is None:
+            return
+        roof[key] = round(float(val), nd) if isinstance(val, float) else val
+
+    for key, name in (("tjds", "tjds"), ("survey_random_model", "survey_random_model"), ("config4", "config4"),
+                      ("pwt_tiled_csr", "pwt_csr"), ("pwt_tiled_tjds", "pwt_tjds")):
+        o = others.get(key)
+        if not o or "frac" not in o:
+            continue
+        put("frac_" + name, o["frac"])
+        put("ms_" + name, o.get("ms_per_product"), 5)
+        put("traffic_over_alg_" + name, o.get("traffic_over_algorithmic"), 3)
+        put("moved_frac_" + name, o.get("moved_frac_of_peak"))
+    for key, name in (("tjds_two_phase", "frac_tjds_colmajor"), ("tjds_atomic", "frac_tjds_atomic")):
+        if key in extra and "frac_of_hbm_peak" in extra[key]:
+            put(name, extra[key]["frac_of_hbm_peak"])
+    c4 = others.get("config4") or {}
+    for k in ("t1_ms", "tN_step_ms", "tN_step_after_ms", "tN_products_only_ms", "speedup_overlapped", "speedup_after",
+              "speedup_products_only", "chunks_chosen"):
+        put("config4_" + k, c4.get(k))
+    e8 = c4.get("eighth_of_n8") or {}
+    for c, ms in ((e8.get("inputs") or {}).get("product_ms_by_chunks") or {}).items():
+        put("config4_eighth_ms_%schunk" % c, ms)
+    put("config4_eighth_chunks_chosen", e8.get("chosen"))
+    cl = others.get("config4_c_layer") or {}
+    if "error" in cl:
+        put("config4_c_layer_error", str(cl["error"])[:120])
+    for ch in (1, 4):
+        f = cl.get("chunks_%d" % ch) or {}
+        for form, short in (("products_only", "products_only"), ("products_then_allgather", "after"), ("overlapped", "overlapped")):
+            put("config4_c_layer_%s_ms_%dchunk" % (short, ch), (f.get(form) or {}).get("event_ms"))
+        for name, ms in (f.get("overlapped_ms_by_exchange") or {}).items():
+            put("config4_c_layer_overlapped_ms_%dchunk_%s" % (ch, name), ms)
+    for k in ("exchange_rccl_ms", "exchange_copies_ms", "exchange_direct_ms", "exchange_chosen", "rccl_ranks"):
+        put("c_layer_" + k if k in ("exchange_chosen", "rccl_ranks") else k, cl.get(k))
+    hp = others.get("headline_products_only") or {}
+    put("headline_products_only_ms", hp.get("ms_per_product"), 5)
+    for name, e in (others.get("sample_matrices_us_per_product") or {}).items():
+        if not isinstance(e, dict):
+            continue
+        stem = name.replace(".mtx", "")
+        for k, short in (("csr_avg_ms", "csr_us"), ("tjds_avg_ms", "tjds_us"), ("csr_loop_wall_ms_per_product", "csr_loop_wall_us"),
+                         ("tjds_loop_wall_ms_per_product", "tjds_loop_wall_us")):
+            put("%s_%s" % (stem, short), e.get(k), 3)
+    c5 = extra.get("config5_pwt") or {}
+    for k, short in (("csr_ms_per_step", "config5_csr_us"), ("tjds_ms_per_step", "config5_tjds_us"), ("csr_then_tjds_ms_per_step", "config5_both_us")):
+        if k in c5:
+            put(short, c5[k] * 1e3, 3)
+    put("exchange", dist_info.get("exchange"))
+    put("dist_backend", dist_info.get("backend"))
+    put("rccl_ranks", dist_info.get("rccl_ranks"))
+    put("n_gpus", world)
+    put("self_launched", dist_info.get("self_launched"))
+
+
 def roofline_of(res, workload=None):
     achieved = res["alg_bytes_local"] / (res["kernel_ms"] * 1e-3) * 1e-9
     r = {"bound": "hbm", "kernel": res["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -866,9 +1031,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and not args.c_layer_child and not args.pmc_child:
+        # no launcher around this process: it starts its own ranks (before torch or HIP are touched) and relays rank 0's line
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one process per GPU: launch with torch.distributed.run" % args.gpus)
         args.gpus = world
 
     if args.c_layer_child:      # child of rank 0 (N > 1): nothing but the C layer, its result as one JSON line
@@ -1333,6 +1499,20 @@ def main():
             "file prints by default), *_event_pairs = hipEvent pair around each launch, *_loop_wall = host wall of the "
             "whole 1000-product loop / 1000, cpu_* = the reference's serial loop on this host; cache-resident, no HBM claim")
     headline_roofline["others"] = others
+    # what the communicator itself reports (not WORLD_SIZE): every rank adds a one and the sum is what took part
+    dist_info = {"backend": "none (one process, one GPU)", "rccl_ranks": 0, "exchange": "none (one GPU)",
+                 "self_launched": os.environ.get("SMVP_BENCH_SELF_LAUNCHED") == "1"}
+    if dist.is_initialized():
+        one = torch.ones(1, dtype=torch.float64, device="cuda")
+        dist.all_reduce(one)
+        took_part = int(round(float(one[0])))
+        dist_info["backend"] = "nccl (RCCL)" if backend == "nccl" else backend
+        dist_info["rccl_ranks"] = took_part if backend == "nccl" else 0
+        dist_info["ranks_in_group"] = took_part
+        dist_info["exchange"] = ("all_gather_into_tensor of the y blocks over %s, %d ranks; config 4: block-cyclic chunks, gather "
+                                 "behind each chunk's product" % ("RCCL/xGMI" if backend == "nccl" else backend, took_part))
+    flat_keys(headline_roofline, others, extra, world, dist_info)
+    extra["dist"] = dist_info
 
     if rank == 0:
         # what this process leaves behind: its children (the rocprofv3 --pmc passes, the C-layer child) have been waited for;

@@ -209,12 +209,23 @@ typedef struct smvp_tjds smvp_tjds_t; /* device-resident TJDS matrix + launch pl
 int smvp_csr_create(smvp_csr_t **out, int device, int rows, int cols, int nnz,
                     const int *row_ptr, const int *col_ind, const double *val,
                     int mem_kind, const int *host_row_ptr);
+/* The same handle for a ROW BLOCK [first_row, first_row + rows) of a larger matrix -- what one rank of a sharded product
+ * holds (smvp_sharded.hip creates its chunks with it; new design, the reference is one thread): row_ptr is the block's own
+ * (0-based), col_ind stays global.  Plans that go by the distance from the diagonal -- BINNED's near / far split and its
+ * LDS windows of x, AUTO's far share -- then take the diagonal where it lies in the whole matrix: column first_row + r for
+ * local row r.  (Without it every block beyond the first few thousand rows looks all far.)  The results are the same. */
+int smvp_csr_create_block(smvp_csr_t **out, int device, int rows, int cols, int nnz,
+                          const int *row_ptr, const int *col_ind, const double *val,
+                          int mem_kind, const int *host_row_ptr, long long first_row);
 int smvp_csr_set_kernel(smvp_csr_t *h, int kernel, int param); /* param: lanes per row (VECTOR) / nnz per tile (STREAM), 0 = default */
 int smvp_csr_get_kernel(const smvp_csr_t *h, int *kernel, int *param);
 /* What AUTO's choice of COLSWEEP rests on: the share (0 ... 1) of the matrix's gathers that pull their own
  * 128-byte line of x through the L2, estimated on 64 samples of 65536 consecutive entries of col_ind (measured
  * on first use, then kept); -1 for matrices of fewer than 4 M entries, which are not sampled. */
 int smvp_csr_gather_spread(smvp_csr_t *h, double *spread);
+/* What AUTO's choice of BINNED rests on besides the spread: the share (0 ... 1) of the entries further than 4096 from the
+ * diagonal (of the whole matrix: smvp_csr_create_block); measured on first use, then kept; -1 where it could not be. */
+int smvp_csr_far_share(smvp_csr_t *h, double *share);
 /* The timed product, main-cli.c:410-416: d_y[0..rows) = A * d_x[0..cols).  Asynchronous
  * on `stream`; d_y is fully overwritten (no pre-zeroing needed). */
 int smvp_csr_spmv(smvp_csr_t *h, const double *d_x, double *d_y, void *stream);
@@ -289,24 +300,36 @@ void smvp_tjds_destroy(smvp_tjds_t *h);
 /* ------------------------------------------- several GPUs, one host process */
 /* New design (the reference is one CPU thread): the matrix is cut into `ngpus` row blocks balanced by entries
  * (smvp_partition_rows); GPU g holds block g -- cut again into `chunks` row chunks, each its own CSR / TJDS handle --
- * plus all of x and produces its slice of y; RCCL ncclAllGather over xGMI puts the full y on every GPU, chunk c
- * travelling while chunk c+1 is multiplied.  devices NULL = 0 .. ngpus-1.  librccl is dlopen'ed on first use.
+ * plus all of x and produces its slice of y; the exchange (RCCL ncclAllGather or direct peer pushes over xGMI, below) puts
+ * the full y on every GPU, chunk c travelling while chunk c+1 is multiplied.  devices NULL = 0 .. ngpus-1.  librccl is dlopen'ed on first use.
  * (bench.py does the same with one process per GPU.)  No multi-GPU box is available to this project's tests: on
  * hardware the RCCL path has run with ONE GPU only; the N > 1 logic of this layer runs in the test suite through
- * SMVP_EXCHANGE_COPIES with 2 ... 8 virtual ranks on one GPU, the Python layer's through gloo.
+ * SMVP_EXCHANGE_COPIES / _DIRECT with 2 ... 8 virtual ranks on one GPU, the Python layer's through gloo.
  * When a rank fails inside a product its peers' collectives may never complete: smvp_sharded_spmv reports the error and
  * marks the handle unusable (later calls fail at once, smvp_sharded_destroy aborts the communicators instead of waiting). */
 typedef struct smvp_sharded smvp_sharded_t;
-/* How the y blocks travel.  RCCL (default): ncclAllGather over xGMI, one communicator rank per GPU.  COPIES: every
- * rank's thread pushes its chunks into every rank's buffer by device-to-device copies, the ranks ordered by events and
- * a host-side meeting point -- no RCCL, and the device list may name one device several times ("virtual ranks"):
- * the whole N-GPU code path (issuing threads, padded chunks, placement of the gathered pieces, both exchange forms,
- * power iteration) then runs on fewer GPUs than ranks.  A rehearsal and test backend, not the fast path. */
-enum { SMVP_EXCHANGE_RCCL = 0, SMVP_EXCHANGE_COPIES = 1 };
+/* How the y blocks travel (round 5: a measured choice, SURVEY 7 "hard parts" -- a ring all-gather pushes 7 blocks through
+ * one xGMI link, direct pushes use all seven):
+ *   RCCL    ncclAllGather over xGMI into a padded wire buffer, one communicator rank per GPU, then one small kernel per
+ *           GPU places the pieces at their rows;
+ *   COPIES  every rank pushes its chunk STRAIGHT INTO EVERY RANK'S FULL VECTOR with hipMemcpyAsync (peer access; the
+ *           copy engines, no compute unit involved) -- no wire buffer, no padding, no placement pass;
+ *   DIRECT  the same pushes by ONE kernel per chunk whose workgroups store to the peers' vectors over xGMI (one launch
+ *           instead of N copy calls, all links at once);
+ *   AUTO    (default) at handle creation every form that is available -- RCCL needs distinct devices and a librccl that
+ *           loads, the pushes need peer access -- moves one product's y once, timed; the fastest is kept
+ *           (smvp_sharded_exchange_info reports the times, smvp_sharded_set_exchange switches).
+ * COPIES and DIRECT order the ranks with events and a host-side meeting point of the issuing threads, and accept a device
+ * list that names one device several times ("virtual ranks": more ranks than GPUs must be asked for with one of these two
+ * by name): the whole N-GPU code path then runs on a one-GPU box.  All forms give the same bits. */
+enum { SMVP_EXCHANGE_RCCL = 0, SMVP_EXCHANGE_COPIES = 1, SMVP_EXCHANGE_DIRECT = 2, SMVP_EXCHANGE_AUTO = 3 };
 typedef struct smvp_shard_opts {
+    unsigned struct_size; /* sizeof(smvp_shard_opts_t) of the header the caller was built with: set by
+                             smvp_shard_opts_default, checked by the create calls (a caller built against another layout
+                             is refused instead of being misread) */
     int chunks;   /* row chunks per GPU (the granularity of the product / all-gather overlap); 0 = 4 when ngpus > 1, else 1 */
     int balance;  /* 1 (default): blocks and chunks balanced by entries; 0: equal heights */
-    int exchange; /* SMVP_EXCHANGE_*; with COPIES ngpus may exceed the visible devices (devices NULL = g % visible) */
+    int exchange; /* SMVP_EXCHANGE_* (default AUTO); with COPIES / DIRECT ngpus may exceed the visible devices (devices NULL = g % visible) */
 } smvp_shard_opts_t;
 void smvp_shard_opts_default(smvp_shard_opts_t *o);
 int smvp_csr_sharded_create(smvp_sharded_t **out, int ngpus, const int *devices, int rows, int cols, int nnz,
@@ -318,6 +341,14 @@ int smvp_tjds_sharded_create(smvp_sharded_t **out, int ngpus, const int *devices
 int smvp_tjds_sharded_create_ex(smvp_sharded_t **out, int ngpus, const int *devices, const smvp_coo_t *coo,
                                 int rows, int cols, int nnz, const smvp_shard_opts_t *opts);
 int smvp_sharded_set_csr_kernel(smvp_sharded_t *h, int kernel, int param); /* smvp_csr_set_kernel on every chunk */
+/* The exchange of one product's y (every chunk, nothing to overlap with), timed `reps` times under every available form;
+ * a handle created with AUTO then keeps the fastest.  Called by the create calls for AUTO (reps = 3). */
+int smvp_sharded_probe_exchange(smvp_sharded_t *h, int reps);
+/* active: the SMVP_EXCHANGE_* in use; available: bit e set = form e can be selected; ms[3]: milliseconds of the last probe by
+ * form (RCCL, COPIES, DIRECT; < 0: not measured); rccl_ranks: what the communicator itself reports (ncclCommCount), 0
+ * without one.  NULL = skip. */
+int smvp_sharded_exchange_info(const smvp_sharded_t *h, int *active, int *available, double *ms, int *rccl_ranks);
+int smvp_sharded_set_exchange(smvp_sharded_t *h, int exchange); /* one of the available forms (not AUTO) */
 int smvp_sharded_set_x(smvp_sharded_t *h, const double *x_host); /* NULL = ones; replicated to every GPU */
 /* One product, asynchronous: the chunk products on every GPU and, by `allgather`, the exchange of y:
  * 0 none; SMVP_GATHER_OVERLAPPED: chunk c is gathered (communication stream) while chunk c+1 is multiplied;
@@ -336,6 +367,9 @@ void smvp_sharded_destroy(smvp_sharded_t *h);
 
 /* ------------------------------------------------ reference-shaped entry points */
 typedef struct smvp_run_opts {
+    unsigned struct_size; /* sizeof(smvp_run_opts_t) of the caller's header: set by smvp_run_opts_default, checked by the
+                             compute calls -- a struct that was never passed through smvp_run_opts_default, or was built
+                             against another layout, is refused with SMVP_ERR_INVALID instead of being misread */
     int device;         /* HIP device ordinal */
     int csr_kernel;     /* SMVP_CSR_KERNEL_* */
     int csr_param;      /* 0 = default */
@@ -347,7 +381,7 @@ typedef struct smvp_run_opts {
     int normalize;      /* with iterate: divide every iterate by its largest magnitude (keeps 1000 steps finite) */
     int tjds_mode;      /* SMVP_TJDS_MODE_* for smvp_tjds_compute (AUTO = ROW_GATHER) */
     int timing;         /* SMVP_TIMING_*: how each product is timed */
-    int shard_exchange; /* ngpus > 1: SMVP_EXCHANGE_* (COPIES: ngpus may exceed the visible GPUs -- virtual ranks) */
+    int shard_exchange; /* ngpus > 1: SMVP_EXCHANGE_* (default AUTO; COPIES / DIRECT: ngpus may exceed the visible GPUs -- virtual ranks) */
     const double *x;    /* host operand, NULL = all ones (main-cli.c:368-369) */
 } smvp_run_opts_t;
 void smvp_run_opts_default(smvp_run_opts_t *o);

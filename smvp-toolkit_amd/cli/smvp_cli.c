@@ -45,13 +45,13 @@
 
 enum { ALG_NONE = 0, ALG_CSR = 1 << 1, ALG_TJDS = 1 << 2, ALG_CISR = 1 << 3, ALG_ALL = 256 };
 enum { OPT_DEVICE = 1000, OPT_QUIRKS, OPT_KERNEL, OPT_USAGE, OPT_DEVCONV, OPT_GPUS, OPT_ITERATE, OPT_NORMALIZE, OPT_TIMING,
-       OPT_TJDS_MODE, OPT_EXPAND, OPT_CACHE, OPT_X, OPT_DUMP, OPT_VIRTUAL };
+       OPT_TJDS_MODE, OPT_EXPAND, OPT_CACHE, OPT_X, OPT_DUMP, OPT_VIRTUAL, OPT_EXCHANGE };
 
 static void usage(FILE *to, const char *prog)
 {
     fprintf(to,
             "Usage: %s [-acgt?] [-a|--all-algs] [-c|--csr] [-g|--cisr-gen] [-t|--tjds]\n"
-            "        [-n|--number=1000] [-s|--slots=16] [-d|--dir=./] [--device=0] [--gpus=1] [--virtual-gpus]\n"
+            "        [-n|--number=1000] [-s|--slots=16] [-d|--dir=./] [--device=0] [--gpus=1] [--exchange=auto] [--virtual-gpus]\n"
             "        [--ref-quirks] [--iterate] [--normalize] [--device-convert] [--csr-kernel=auto|vector|stream|stream-carry|colsweep|binned]\n"
             "        [--tjds-mode=auto|row-gather|two-phase|atomic] [--timing=auto|events|device]\n"
             "        [--expand-symmetric] [--cache] [--x=ones|random] [--dump-arrays]\n"
@@ -71,9 +71,11 @@ static void help(const char *prog)
     puts("  -s, --slots=16           Number of slots for CISR.");
     puts("  -d, --dir=./             Output folder for reports.");
     puts("      --device=0           HIP device ordinal.");
-    puts("      --gpus=1             Shard the matrix by row blocks over this many GPUs (RCCL all-gather of y;");
+    puts("      --gpus=1             Shard the matrix by row blocks over this many GPUs (all-gather of y after each product;");
     puts("                           so far verified on hardware with one GPU only).");
-    puts("      --virtual-gpus       --gpus N with the y blocks exchanged by device-to-device copies instead of RCCL:");
+    puts("      --exchange=auto      How the blocks of y travel: rccl (ncclAllGather), copies (peer hipMemcpyAsync), direct");
+    puts("                           (one push kernel per chunk), auto (times each when the blocks are created, keeps the fastest).");
+    puts("      --virtual-gpus       --gpus N with the y blocks exchanged by peer pushes instead of RCCL:");
     puts("                           N may exceed the GPUs present (the ranks share them) -- a rehearsal of the N-GPU path.");
     puts("      --iterate            Power iteration: feed each result back as the next operand (x <- A x, n times).");
     puts("      --normalize          --iterate, and divide every iterate by its largest magnitude.");
@@ -282,13 +284,13 @@ int main(int argc, char *argv[])
         {"timing", required_argument, NULL, OPT_TIMING}, {"tjds-mode", required_argument, NULL, OPT_TJDS_MODE},
         {"expand-symmetric", no_argument, NULL, OPT_EXPAND}, {"cache", no_argument, NULL, OPT_CACHE},
         {"x", required_argument, NULL, OPT_X}, {"dump-arrays", no_argument, NULL, OPT_DUMP},
-        {"virtual-gpus", no_argument, NULL, OPT_VIRTUAL},
+        {"virtual-gpus", no_argument, NULL, OPT_VIRTUAL}, {"exchange", required_argument, NULL, OPT_EXCHANGE},
         {NULL, 0, NULL, 0}};
     const char *prog = "smvp-toolkit-cli";
     int alg_mode = ALG_NONE, calc_iter = 1000, cisr_slots = 16, device = 0, quirks = 0;
     int csr_kernel = SMVP_CSR_KERNEL_AUTO, device_convert = 0, ngpus = 1, iterate = 0, normalize = 0;
     int timing = SMVP_TIMING_AUTO, tjds_mode = SMVP_TJDS_MODE_AUTO, expand = 0, use_cache = 0, x_random = 0, dump = 0;
-    int virtual_gpus = 0;
+    int virtual_gpus = 0, exchange = SMVP_EXCHANGE_AUTO;
     const char *report_dir = "";
 
     if (argc < 2) { /* main-cli.c:1267-1271 */
@@ -361,6 +363,18 @@ int main(int argc, char *argv[])
             break;
         case OPT_VIRTUAL:
             virtual_gpus = 1;
+            break;
+        case OPT_EXCHANGE:
+            if (strcmp(optarg, "auto") == 0)
+                exchange = SMVP_EXCHANGE_AUTO;
+            else if (strcmp(optarg, "rccl") == 0)
+                exchange = SMVP_EXCHANGE_RCCL;
+            else if (strcmp(optarg, "copies") == 0)
+                exchange = SMVP_EXCHANGE_COPIES;
+            else if (strcmp(optarg, "direct") == 0)
+                exchange = SMVP_EXCHANGE_DIRECT;
+            else
+                die("Invalid exchange specified (auto, rccl, copies or direct).");
             break;
         case OPT_KERNEL:
             if (strcmp(optarg, "auto") == 0)
@@ -567,9 +581,15 @@ int main(int argc, char *argv[])
             engine_fail("Selecting the GPU", rc);
         printf(CYAN "[DATA]\tCompute device %d: " RESET "%s, %d CUs, %.0f GiB\n", device, name, cus,
                (double)mem / (1024.0 * 1024.0 * 1024.0));
-        if (ngpus > 1)
+        if (virtual_gpus && (exchange == SMVP_EXCHANGE_AUTO || exchange == SMVP_EXCHANGE_RCCL))
+            exchange = SMVP_EXCHANGE_DIRECT; /* ranks that share a GPU: peer pushes (RCCL wants one rank per device) */
+        if (ngpus > 1) {
+            static const char *how[] = {"RCCL all-gather", "peer copies (hipMemcpyAsync) straight into every GPU's copy",
+                                        "peer pushes (one kernel per chunk) straight into every GPU's copy",
+                                        "RCCL all-gather or peer pushes, whichever is faster here (timed when the blocks are created)"};
             printf(CYAN "[DATA]\tRow blocks on %d %sGPUs, " RESET "%s of the result vector after each product\n", ngpus,
-                   virtual_gpus ? "virtual " : "", virtual_gpus ? "exchange by device-to-device copies" : "RCCL all-gather");
+                   virtual_gpus ? "virtual " : "", how[exchange]);
+        }
     }
 
     smvp_run_opts_t opts;
@@ -583,7 +603,7 @@ int main(int argc, char *argv[])
     opts.normalize = normalize;
     opts.timing = timing;
     opts.tjds_mode = tjds_mode;
-    opts.shard_exchange = virtual_gpus ? SMVP_EXCHANGE_COPIES : SMVP_EXCHANGE_RCCL;
+    opts.shard_exchange = exchange;
     opts.x = x_operand;
     smvp_time_stats_t st;
     char path[4096];

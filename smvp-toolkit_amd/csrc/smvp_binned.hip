@@ -407,7 +407,7 @@ __device__ __forceinline__ int row_of_entry(const int *__restrict__ row_ptr, int
 
 // flag[e] = 1 where |column - row| > band; row_of[e] (optional)
 __global__ __launch_bounds__(256) void bin_classify(const int *__restrict__ row_ptr, const int *__restrict__ col_ind, int rows,
-                                                    int nnz, int band, int *__restrict__ flag, int *__restrict__ row_of)
+                                                    int nnz, int band, long long row0, int *__restrict__ flag, int *__restrict__ row_of)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e > nnz)
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void bin_classify(const int *__restrict__ row_
         return;
     }
     const int r = row_of_entry(row_ptr, rows, e);
-    const long long d = (long long)col_ind[e] - r;
+    const long long d = (long long)col_ind[e] - (row0 + r);  // the diagonal of the WHOLE matrix: row0 = this block's first global row
     flag[e] = (d > band || -d > band) ? 1 : 0;
     if (row_of)
         row_of[e] = r;
@@ -711,7 +711,7 @@ void free_binned_plan(BinnedPlan *p)
     *p = BinnedPlan();
 }
 
-int csr_far_share(const int *d_row_ptr, const int *d_col_ind, int rows, int nnz, int band, double *share, hipStream_t st)
+int csr_far_share(const int *d_row_ptr, const int *d_col_ind, int rows, int nnz, int band, long long row0, double *share, hipStream_t st)
 {
     *share = 0.0;
     if (nnz <= 0 || rows <= 0)
@@ -721,7 +721,7 @@ int csr_far_share(const int *d_row_ptr, const int *d_col_ind, int rows, int nnz,
     HIP_TRY(sc.get(&flag, (size_t)nnz + 1));
     HIP_TRY(sc.get(&fpos, (size_t)nnz + 1));
     hipLaunchKernelGGL(bin_classify, dim3(blocks_for((long long)nnz + 1)), dim3(256), 0, st, d_row_ptr, d_col_ind, rows, nnz, band,
-                       flag, (int *)nullptr);
+                       row0, flag, (int *)nullptr);
     HIP_TRY(hipGetLastError());
     if (int rc = scan_exclusive(flag, fpos, (size_t)nnz + 1, sc, st))
         return rc;
@@ -742,17 +742,19 @@ __global__ __launch_bounds__(256) void bin_capped_rows(const int *__restrict__ r
 }
 
 int build_binned_plan(const int *d_row_ptr, const int *d_col_ind, const double *d_val, int rows, int cols, int nnz, int band,
-                      bool near_window, BinnedPlan *out, hipStream_t st)
+                      long long row0, bool near_window, BinnedPlan *out, hipStream_t st)
 {
     free_binned_plan(out);
     BinnedPlan &P = *out;
     P.band = band > 0 ? band : kBinNearBand;
+    P.row0 = row0;
     P.slots = kBinSlots, P.threads_b = kBinThreads;
     if (const char *e = getenv("SMVP_BINNED_SLOTS")) {  // development switches (plan time): pass B's block size and workgroup
         const int v = atoi(e);
-        if (v == 8192 || v == 4096 || v == 2048)
+        if (v == 8192 || v == 4096 || v == 2048) {  // (any other value is ignored)
             P.slots = v;
-        P.threads_b = v == 8192 ? 1024 : v == 4096 ? 512 : 256;
+            P.threads_b = v == 8192 ? 1024 : v == 4096 ? 512 : 256;
+        }
     }
     const int bucket = P.slots - P.slots / 8;
     P.rows = rows, P.cols = cols, P.nnz = nnz;
@@ -776,7 +778,7 @@ int build_binned_plan(const int *d_row_ptr, const int *d_col_ind, const double *
     HIP_TRY(sc.get(&fpos, (size_t)nnz + 1));
     HIP_TRY(sc.get(&row_of, (size_t)nnz));
     hipLaunchKernelGGL(bin_classify, dim3(blocks_for((long long)nnz + 1)), dim3(256), 0, st, d_row_ptr, d_col_ind, rows, nnz, P.band,
-                       flag, row_of);
+                       row0, flag, row_of);
     HIP_TRY(hipGetLastError());
     if (int rc = scan_exclusive(flag, fpos, (size_t)nnz + 1, sc, st))
         return rc;
@@ -814,7 +816,7 @@ int build_binned_plan(const int *d_row_ptr, const int *d_col_ind, const double *
     auto window = [&]() -> int {
         if (!near_window)
             return SMVP_OK;
-        if (int rc = build_near_window(P.near_ptr, P.near_col, P.near_val, capped, rows, cols, P.nnz_near, P.band, &P.nw, st))
+        if (int rc = build_near_window(P.near_ptr, P.near_col, P.near_val, capped, rows, cols, P.nnz_near, P.band, row0, &P.nw, st))
             return rc;
         if (P.nw.on) {
             (void)hipFree(P.near_col);
@@ -889,7 +891,8 @@ int build_binned_plan(const int *d_row_ptr, const int *d_col_ind, const double *
     return window();
 }
 
-// more than 64 KB of dynamic LDS must be asked for, once per device
+// more than 64 KB of dynamic LDS must be asked for, once per device (the answer is remembered for ordinals below 64; beyond
+// that the question is simply asked again)
 static hipError_t ask_for_lds()
 {
     int dev = 0;
@@ -897,16 +900,22 @@ static hipError_t ask_for_lds()
     if (e != hipSuccess)
         return e;
     static std::atomic<unsigned long long> asked{0};
-    if (dev < 64 && !(asked.load() >> dev & 1ull)) {
+    if (dev >= 64 || !(asked.load() >> dev & 1ull)) {
         e = hipFuncSetAttribute((const void *)csr_binned_far_products<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsA);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)csr_binned_far_sums<8192, 1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b_bytes(8192));
-
         if (e != hipSuccess)
             return e;
-        asked.fetch_or(1ull << dev);
+        if (dev < 64)
+            asked.fetch_or(1ull << dev);
     }
     return hipSuccess;
+}
+
+hipError_t binned_reserve_lds()
+{
+    const hipError_t e = ask_for_lds();
+    return e != hipSuccess ? e : near_window_reserve_lds();
 }
 
 // pass A: every far product into the bins (reads x; independent of the near product, which may run beside it)

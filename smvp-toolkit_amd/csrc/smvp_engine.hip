@@ -107,6 +107,8 @@ int upload(T **dst, const std::vector<T> &src)
 struct smvp_csr {
     int device = 0;
     int rows = 0, cols = 0, nnz = 0;
+    long long row0 = 0;  // global number of this handle's first row (a row block of a sharded matrix; 0 for a whole matrix):
+                         // where the diagonal lies -- the binned plan's near / far split and its windows of x go by it
     int *d_row_ptr = nullptr;
     int *d_col_ind = nullptr;
     double *d_val = nullptr;
@@ -325,7 +327,7 @@ bool binned_suits(smvp_csr *h)
         return false;
     if (h->far_share < -1.5) {
         double share = -1.0;
-        if (smvp::csr_far_share(h->d_row_ptr, h->d_col_ind, h->rows, h->nnz, smvp::kBinNearBand, &share, nullptr) != SMVP_OK) {
+        if (smvp::csr_far_share(h->d_row_ptr, h->d_col_ind, h->rows, h->nnz, smvp::kBinNearBand, h->row0, &share, nullptr) != SMVP_OK) {
             (void)hipGetLastError();
             share = -1.0;
         }
@@ -545,7 +547,7 @@ static double wall_ms();
 static int csr_create_impl(smvp_csr_t **out, int device, int rows, int cols, int nnz,
                            const int *row_ptr, const int *col_ind, const double *val,
                            int mem_kind, const int *host_row_ptr, int flavor, const TjdsSource *src = nullptr,
-                           bool plain_only = false)
+                           bool plain_only = false, long long first_row = 0)
 {
     const bool unit_val = flavor == smvp::kFlavorUnit;
     const bool plain = flavor == smvp::kFlavorCsr;
@@ -564,6 +566,7 @@ static int csr_create_impl(smvp_csr_t **out, int device, int rows, int cols, int
     h->device = device;
     h->flavor = flavor;
     h->plain_only = plain_only;
+    h->row0 = first_row;
     if (src) {
         h->d_pos = src->pos, h->d_start_pos = src->start_pos;
         h->num_diag = src->num_diag;
@@ -639,6 +642,38 @@ extern "C" int smvp_csr_create(smvp_csr_t **out, int device, int rows, int cols,
     return csr_create_impl(out, device, rows, cols, nnz, row_ptr, col_ind, val, mem_kind, host_row_ptr, smvp::kFlavorCsr);
 }
 
+// A row block [first_row, first_row + rows) of a larger matrix (what a rank of a sharded product holds): the same handle,
+// but plans that go by the distance from the diagonal -- the binned plan's near / far split, its windows of x, AUTO's
+// far share -- take the diagonal where it really lies.  Without this every block beyond the first 4096 rows looked all far.
+extern "C" int smvp_csr_create_block(smvp_csr_t **out, int device, int rows, int cols, int nnz,
+                                     const int *row_ptr, const int *col_ind, const double *val,
+                                     int mem_kind, const int *host_row_ptr, long long first_row)
+{
+    if (first_row < 0)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create_block: first_row < 0");
+    return csr_create_impl(out, device, rows, cols, nnz, row_ptr, col_ind, val, mem_kind, host_row_ptr, smvp::kFlavorCsr, nullptr,
+                           false, first_row);
+}
+
+// share (0 ... 1) of the entries further than the binned plan's default band from the diagonal: what AUTO's choice rests on
+extern "C" int smvp_csr_far_share(smvp_csr_t *h, double *share)
+{
+    if (!h || !share)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_far_share: bad argument");
+    DeviceScope on(h->device);
+    if (h->far_share < -1.5) {
+        double s = -1.0;
+        if (h->flavor != smvp::kFlavorCsr ||
+            smvp::csr_far_share(h->d_row_ptr, h->d_col_ind, h->rows, h->nnz, smvp::kBinNearBand, h->row0, &s, nullptr) != SMVP_OK) {
+            (void)hipGetLastError();
+            s = -1.0;
+        }
+        h->far_share = s;
+    }
+    *share = h->far_share;
+    return SMVP_OK;
+}
+
 static double wall_ms()
 {
     timespec t;
@@ -651,10 +686,16 @@ static double wall_ms()
 static int build_binned(smvp_csr *h, int band)
 {
     free_binned(h);
+    // both passes (and K6) ask for more than 64 KB of dynamic LDS: a device that refuses makes the PLAN fail here -- AUTO then
+    // falls back to the tile kernel (csr_create_impl) -- instead of every later product
+    if (hipError_t le = smvp::binned_reserve_lds(); le != hipSuccess) {
+        (void)hipGetLastError();
+        return smvp::fail(SMVP_ERR_UNSUPPORTED, "the binned plan needs 154 KB of LDS per workgroup: %s", hipGetErrorString(le));
+    }
     bool window = true;
     if (const char *e = getenv("SMVP_BINNED_NEAR"))  // development switch (plan time): "tile" keeps the near part on the tile kernel
         window = strcmp(e, "tile") != 0;
-    if (int rc = smvp::build_binned_plan(h->d_row_ptr, h->d_col_ind, h->d_val, h->rows, h->cols, h->nnz, band, window, &h->bin, nullptr))
+    if (int rc = smvp::build_binned_plan(h->d_row_ptr, h->d_col_ind, h->d_val, h->rows, h->cols, h->nnz, band, h->row0, window, &h->bin, nullptr))
         return rc;
     if (h->bin.nw.on) {
         const char *e = getenv("SMVP_BINNED_OVERLAP");  // development switch (plan time): 0 = pass A behind the near part, one stream
@@ -666,7 +707,7 @@ static int build_binned(smvp_csr *h, int band)
         return SMVP_OK;
     }
     return csr_create_impl(&h->near, h->device, h->rows, h->cols, h->bin.nnz_near, h->bin.near_ptr, h->bin.near_col, h->bin.near_val,
-                           SMVP_MEM_DEVICE, nullptr, smvp::kFlavorCsr, nullptr, true);
+                           SMVP_MEM_DEVICE, nullptr, smvp::kFlavorCsr, nullptr, true, h->row0);
 }
 
 extern "C" int smvp_csr_set_kernel(smvp_csr_t *h, int kernel, int param)
@@ -769,11 +810,22 @@ static int csr_spmv_impl(smvp_csr_t *h, const double *d_x, double *d_y, void *st
             e = smvp::launch_binned_products(h->bin, d_x, h->side);
             if (e != hipSuccess)
                 return smvp::fail(SMVP_ERR_HIP, "CSR launch failed: %s", hipGetErrorString(e));
-            HIP_TRY(hipEventRecord(h->ev_join, h->side));
-            e = smvp::launch_near_window(h->bin.nw, d_x, d_y, st);
-            if (e != hipSuccess)
-                return smvp::fail(SMVP_ERR_HIP, "CSR launch failed: %s", hipGetErrorString(e));
-            HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
+            // From here on pass A is in flight on the side stream, reading x and writing the bins: whatever fails below, the
+            // caller's stream is joined to it before the error goes back -- the caller may free x or destroy the handle next.
+            int rc = SMVP_OK;
+            hipError_t je = hipEventRecord(h->ev_join, h->side);
+            if (je == hipSuccess) {
+                e = smvp::launch_near_window(h->bin.nw, d_x, d_y, st);
+                if (e != hipSuccess)
+                    rc = smvp::fail(SMVP_ERR_HIP, "CSR launch failed: %s", hipGetErrorString(e));
+                je = hipStreamWaitEvent(st, h->ev_join, 0);
+            }
+            if (je != hipSuccess) {
+                (void)hipStreamSynchronize(h->side);  // the join could not be enqueued: wait for pass A here
+                return smvp::fail(SMVP_ERR_HIP, "joining the binned plan's side stream failed: %s", hipGetErrorString(je));
+            }
+            if (rc != SMVP_OK)
+                return rc;
             e = smvp::launch_binned_sums(h->bin, d_y, st);
             if (e != hipSuccess)
                 return smvp::fail(SMVP_ERR_HIP, "CSR launch failed: %s", hipGetErrorString(e));
@@ -1387,6 +1439,8 @@ extern "C" void smvp_run_opts_default(smvp_run_opts_t *o)
     if (!o)
         return;
     memset(o, 0, sizeof *o);
+    o->struct_size = (unsigned)sizeof *o;
+    o->shard_exchange = SMVP_EXCHANGE_AUTO;
     o->csr_kernel = SMVP_CSR_KERNEL_AUTO;
     o->tjds_mode = SMVP_TJDS_MODE_AUTO;
     o->timing = SMVP_TIMING_AUTO;
@@ -1484,6 +1538,10 @@ int finish_run(RunScratch &s, int rows, int iters, double *y, double *time_each_
 
 int check_iterate(const smvp_run_opts_t *o, int rows, int cols)
 {
+    if (o->struct_size != (unsigned)sizeof(smvp_run_opts_t))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_run_opts_t of %u bytes, this library's has %u: initialise it with "
+                                            "smvp_run_opts_default and build against this library's header",
+                          o->struct_size, (unsigned)sizeof(smvp_run_opts_t));
     if (o->iterate && rows != cols)
         return smvp::fail(SMVP_ERR_INVALID, "power iteration needs a square matrix (%d x %d given)", rows, cols);
     if (o->timing < SMVP_TIMING_AUTO || o->timing > SMVP_TIMING_DEVICE)

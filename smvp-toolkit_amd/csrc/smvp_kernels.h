@@ -108,6 +108,7 @@ constexpr int kNwLongCap = 1024;   // long rows a block may hold (their list and
 struct NearWindow {
     bool on = false;
     int rows = 0, cols = 0, nblocks = 0, n_out = 0;
+    long long row0 = 0;                            // global number of the handle's first row: the window of local block b starts at row0 + b * 8192 - band
     long long slots = 0;                           // entries of the streams (64 per step)
     int *wave_ptr = nullptr;                       // nblocks * 16 + 1: first step of every wavefront's run
     int *wave_n1 = nullptr, *wave_n2 = nullptr;    // steps of its short slices / of its long rows
@@ -124,12 +125,13 @@ void free_near_window(NearWindow *p);
 // the near CSR arrays of a binned plan -> the window plan; `capped[r]` != 0 marks a row that keeps entries outside the band.
 // out->on stays false (and SMVP_OK is returned) where the plan does not suit: band > kNwBand, a block with too many long rows
 int build_near_window(const int *near_ptr, const int *near_col, const double *near_val, const int *capped, int rows, int cols,
-                      int nnz_near, int band, NearWindow *out, hipStream_t stream);
+                      int nnz_near, int band, long long row0, NearWindow *out, hipStream_t stream);
 // y[r] = the near part's sum for EVERY row r (0 without near entries)
 hipError_t launch_near_window(const NearWindow &p, const double *x, double *y, hipStream_t stream);
 
 struct BinnedPlan {
     int band = kBinNearBand;
+    long long row0 = 0;  // global number of the handle's first row (a row block of a sharded matrix): "far" is |column - (row0 + row)| > band
     int rows = 0, cols = 0, nnz = 0, nnz_near = 0, nf = 0;  // nf: far entries
     int ncb = 0, nrb = 0, q = 1, nfr = 0, splits = 1;       // column blocks, row blocks, row blocks per super block, far rows
     int slots = kBinSlots, threads_b = kBinThreads;          // pass B: far entries per row block at most (a row's cap is an eighth of it), threads per workgroup
@@ -150,12 +152,15 @@ void free_binned_plan(BinnedPlan *p);
 // near / far split of a device-resident CSR matrix and the far part's two streams, built on the device
 // near_window: build the near part's window plan where it suits (out->nw.on tells)
 int build_binned_plan(const int *d_row_ptr, const int *d_col_ind, const double *d_val, int rows, int cols, int nnz, int band,
-                      bool near_window, BinnedPlan *out, hipStream_t stream);
+                      long long row0, bool near_window, BinnedPlan *out, hipStream_t stream);
 // far products into the bins (pass A: needs x only); y[row] += the row's far sum for every row with far entries (pass B:
 // after pass A, and after the near product has written y)
+// asks the current device for the > 64 KB of dynamic LDS the three kernels of the plan use (once per device; hipSuccess: granted)
+hipError_t binned_reserve_lds();
+hipError_t near_window_reserve_lds();
 hipError_t launch_binned_products(const BinnedPlan &p, const double *x, hipStream_t stream);
 hipError_t launch_binned_sums(const BinnedPlan &p, double *y, hipStream_t stream);
 // share (0 ... 1) of a CSR matrix's entries with |column - row| > band: what AUTO's choice of the binned plan rests on
-int csr_far_share(const int *d_row_ptr, const int *d_col_ind, int rows, int nnz, int band, double *share, hipStream_t stream);
+int csr_far_share(const int *d_row_ptr, const int *d_col_ind, int rows, int nnz, int band, long long row0, double *share, hipStream_t stream);
 
 }  // namespace smvp

@@ -70,7 +70,7 @@ __device__ __forceinline__ double wave_sum_fixed(double v)
 }
 
 __global__ __launch_bounds__(kThreads) void csr_near_window(const double *__restrict__ x, double *__restrict__ y, int rows, int cols,
-                                                           int nblocks, const int *__restrict__ wave_ptr, const int *__restrict__ wave_n1,
+                                                           long long row0, int nblocks, const int *__restrict__ wave_ptr, const int *__restrict__ wave_n1,
                                                            const int *__restrict__ wave_n2, const unsigned short *__restrict__ perm16,
                                                            const double *__restrict__ sval, const unsigned short *__restrict__ sword,
                                                            const int *__restrict__ blk_long_ptr,
@@ -88,9 +88,9 @@ __global__ __launch_bounds__(kThreads) void csr_near_window(const double *__rest
     const int b = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (b >= nblocks)
         return;
-    const long long R0 = (long long)b * kRB;
-    const long long wbase = R0 - kBand > 0 ? R0 - kBand : 0;
-    const long long wend = R0 + kRB + kBand < (long long)cols ? R0 + kRB + kBand : (long long)cols;
+    const long long R0 = (long long)b * kRB;  // the block's first LOCAL row; the diagonal it sits on is column row0 + R0
+    const long long wbase = row0 + R0 - kBand > 0 ? row0 + R0 - kBand : 0;
+    const long long wend = row0 + R0 + kRB + kBand < (long long)cols ? row0 + R0 + kRB + kBand : (long long)cols;
     const int wlen = wend > wbase ? (int)(wend - wbase) : 0;
 
     const int gw = b * kWaves + wave;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void nw_wave_steps(const unsigned *__restrict_
 __global__ __launch_bounds__(256) void nw_emit_short(const unsigned *__restrict__ skey, const unsigned *__restrict__ order,
                                                      const int *__restrict__ near_ptr, const int *__restrict__ near_col,
                                                      const double *__restrict__ near_val, const int *__restrict__ wave_ptr, int rows,
-                                                     unsigned short *__restrict__ perm16, double *__restrict__ sval,
+                                                     long long row0, unsigned short *__restrict__ perm16, double *__restrict__ sval,
                                                      unsigned short *__restrict__ sword)
 {
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void nw_emit_short(const unsigned *__restrict_
     for (int ii = 0; ii < i; ++ii)
         off += slice_width(skey, (long long)b * kSlices + w + kWaves * ii, rows);
     const int a = near_ptr[r], len = is_short ? near_ptr[r + 1] - a : 0;
-    const long long wbase = (long long)b * kRB - kBand > 0 ? (long long)b * kRB - kBand : 0;
+    const long long wbase = row0 + (long long)b * kRB - kBand > 0 ? row0 + (long long)b * kRB - kBand : 0;
     for (int e = 0; e < len; ++e) {
         const long long d = (off + e) * 64 + lane;
         sval[d] = near_val[a + e];
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void nw_emit_short(const unsigned *__restrict_
 __global__ __launch_bounds__(256) void nw_emit_long(const int *__restrict__ long_row, const int *__restrict__ blk_long_ptr,
                                                     const int *__restrict__ near_ptr, const int *__restrict__ near_col,
                                                     const double *__restrict__ near_val, const int *__restrict__ wave_ptr,
-                                                    const int *__restrict__ wave_n1, int nlong, double *__restrict__ sval,
+                                                    const int *__restrict__ wave_n1, int nlong, long long row0, double *__restrict__ sval,
                                                     unsigned short *__restrict__ sword)
 {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void nw_emit_long(const int *__restrict__ long
         off += (near_ptr[rr + 1] - near_ptr[rr] + 63) / 64;
     }
     const int a = near_ptr[r], len = near_ptr[r + 1] - a, steps = (len + 63) / 64;
-    const long long wbase = (long long)b * kRB - kBand > 0 ? (long long)b * kRB - kBand : 0;
+    const long long wbase = row0 + (long long)b * kRB - kBand > 0 ? row0 + (long long)b * kRB - kBand : 0;
     for (int j = lane; j < steps * 64; j += 64) {
         const long long d = (off + j / 64) * 64 + lane;
         int word = j / 64 == steps - 1 ? kEnd : 0;
@@ -427,13 +427,13 @@ void free_near_window(NearWindow *p)
 // `capped[r]` != 0: row r keeps entries outside the band (it goes to the outside list).  *out stays off (and SMVP_OK is
 // returned) where the plan does not suit the matrix.
 int build_near_window(const int *near_ptr, const int *near_col, const double *near_val, const int *capped, int rows, int cols,
-                      int nnz_near, int band, NearWindow *out, hipStream_t st)
+                      int nnz_near, int band, long long row0, NearWindow *out, hipStream_t st)
 {
     free_near_window(out);
     if (rows <= 0 || nnz_near <= 0 || band > kBand)
         return SMVP_OK;
     NearWindow P;
-    P.rows = rows, P.cols = cols;
+    P.rows = rows, P.cols = cols, P.row0 = row0;
     P.nblocks = (int)(((long long)rows + kRB - 1) / kRB);
     const int nwaves = P.nblocks * kWaves;
     const size_t padded_rows = (size_t)P.nblocks * kRB;
@@ -538,10 +538,10 @@ int build_near_window(const int *near_ptr, const int *near_col, const double *ne
     HIP_TRY(hipMemsetAsync(P.sword, 0, std::max<size_t>((size_t)P.slots, 4) * sizeof(unsigned short), st));
     HIP_TRY(hipMemsetAsync(P.perm16, 0xff, std::max<size_t>(padded_rows, 4) * sizeof(unsigned short), st));
     hipLaunchKernelGGL(nw_emit_short, dim3(blocks_for(rows)), dim3(256), 0, st, k1, i1, near_ptr, near_col, near_val, P.wave_ptr, rows,
-                       P.perm16, P.sval, P.sword);
+                       row0, P.perm16, P.sval, P.sword);
     if (nlong > 0)
         hipLaunchKernelGGL(nw_emit_long, dim3((unsigned)((nlong + 3) / 4)), dim3(256), 0, st, long_row, P.blk_long_ptr, near_ptr, near_col,
-                           near_val, P.wave_ptr, P.wave_n1, nlong, P.sval, P.sword);
+                           near_val, P.wave_ptr, P.wave_n1, nlong, row0, P.sval, P.sword);
     if (n_out > 0)
         hipLaunchKernelGGL(nw_emit_outside, dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, st, P.out_row, P.out_ptr, near_ptr, near_col,
                            near_val, n_out, P.out_col, P.out_val);
@@ -553,7 +553,7 @@ int build_near_window(const int *near_ptr, const int *near_col, const double *ne
     return SMVP_OK;
 }
 
-hipError_t launch_near_window(const NearWindow &p, const double *x, double *y, hipStream_t stream)
+hipError_t near_window_reserve_lds()
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -567,8 +567,16 @@ hipError_t launch_near_window(const NearWindow &p, const double *x, double *y, h
         if (dev < 64)
             asked.fetch_or(1ull << dev);
     }
+    return hipSuccess;
+}
+
+hipError_t launch_near_window(const NearWindow &p, const double *x, double *y, hipStream_t stream)
+{
+    hipError_t e = near_window_reserve_lds();
+    if (e != hipSuccess)
+        return e;
     hipLaunchKernelGGL(csr_near_window, dim3((unsigned)((p.nblocks + 7) / 8 * 8)), dim3(kThreads), kLds, stream, x, y, p.rows, p.cols,
-                       p.nblocks, p.wave_ptr,
+                       p.row0, p.nblocks, p.wave_ptr,
                        p.wave_n1, p.wave_n2, p.perm16, p.sval, p.sword, p.blk_long_ptr, p.long_row16);
     if (p.n_out > 0)
         hipLaunchKernelGGL(csr_near_outside_rows, dim3((unsigned)((p.n_out + 3) / 4)), dim3(256), 0, stream, p.n_out, p.out_row, p.out_ptr,

@@ -18,11 +18,15 @@
 // librccl is loaded with dlopen the first time a sharded handle is created, so
 // single-GPU runs neither link nor load it.
 //
-// opts.exchange = SMVP_EXCHANGE_COPIES replaces the RCCL calls by peer copies: every rank's thread pushes its chunk into
-// every rank's wire buffer (hipMemcpyAsync, device to device) and the ranks order themselves with events and a host
-// barrier.  It accepts any device list -- also ONE device several times -- so that the N-GPU code (issuing threads,
-// padded chunks, placement of the gathered pieces across ranks, both exchange forms, power iteration, early destroy)
-// runs on a one-GPU box: "virtual ranks".  It is a rehearsal and test backend, not the fast path over xGMI.
+// How the y blocks travel is a measured choice (round 5; SURVEY 7: a one-link ring costs 0.46 ms against 0.1 ms of product,
+// direct pushes over all seven links 65 us): SMVP_EXCHANGE_RCCL is ncclAllGather into a padded wire buffer + a placement
+// kernel; SMVP_EXCHANGE_COPIES pushes every chunk straight into every rank's full vector with hipMemcpyAsync (the copy
+// engines); SMVP_EXCHANGE_DIRECT does the same pushes with one kernel per chunk (stores over xGMI, all links at once);
+// SMVP_EXCHANGE_AUTO (the default) times one product's exchange under every form that is available when the handle is
+// created and keeps the fastest.  The two push forms order the ranks with events and a host-side meeting point of the
+// issuing threads, need no wire buffer and no placement, and accept any device list -- also ONE device several times --
+// so that the N-GPU code (issuing threads, chunks, both gather modes, power iteration, early destroy) runs on a one-GPU
+// box: "virtual ranks".
 #include "smvp_common.h"
 #include "smvp_kernels.h"
 
@@ -54,6 +58,7 @@ struct Rccl {
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;  // optional
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -90,6 +95,7 @@ int load_rccl(Rccl **out)
         r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
         r.CommAbort = (decltype(r.CommAbort))dlsym(r.lib, "ncclCommAbort");
+        r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");
         if (missing)
             r.why = std::string("missing symbol ") + missing;
         else
@@ -130,6 +136,34 @@ __global__ __launch_bounds__(256) void place_gathered(const double *__restrict__
     y_full[r] = wire[(size_t)seg[lo].z + (size_t)(r - seg[lo].x)];
 }
 
+// SMVP_EXCHANGE_DIRECT: one rank's chunk into every rank's full vector.  blockIdx.y = destination rank: every destination is
+// its own stream of coalesced stores (over that peer's xGMI link; the rank's own copy at HBM speed), the source is re-read
+// from L2.  16-byte stores where source and destination are aligned alike, 8-byte otherwise.
+struct PushTargets {
+    double *y_full[64];
+};
+__global__ __launch_bounds__(256) void push_chunk(const double *__restrict__ src, const PushTargets dst, long long first_row, int count)
+{
+    double *__restrict__ out = dst.y_full[blockIdx.y] + first_row;
+    const int stride = (int)gridDim.x * 256;
+    const int i0 = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int head = (int)(((uintptr_t)src >> 3) & 1u);  // elements in front of the first 16-byte boundary of the source
+    if ((((uintptr_t)out >> 3) & 1u) == (unsigned)head) {
+        if (head && i0 == 0 && count > 0)
+            out[0] = src[0];
+        const int pairs = (count - head) / 2;
+        const double2 *s2 = reinterpret_cast<const double2 *>(src + head);
+        double2 *o2 = reinterpret_cast<double2 *>(out + head);
+        for (int i = i0; i < pairs; i += stride)
+            o2[i] = s2[i];
+        if (i0 == 0 && head + 2 * pairs < count)
+            out[count - 1] = src[count - 1];
+    } else {
+        for (int i = i0; i < count; i += stride)
+            out[i] = src[i];
+    }
+}
+
 }  // namespace
 
 struct smvp_sharded {
@@ -156,7 +190,12 @@ struct smvp_sharded {
     // exchange by copies (virtual ranks): ev_pushed[g] = rank g's pieces of this product have landed everywhere,
     // ev_placed[g] = rank g has read its wire buffer (it may be written again); `phase` lines the issuing threads up
     // between recording those events and waiting for them
-    int exchange = SMVP_EXCHANGE_RCCL;
+    int exchange = SMVP_EXCHANGE_RCCL;  // the form in use: never AUTO
+    bool auto_exchange = false;         // created with AUTO: a probe keeps the fastest form
+    bool have_rccl = false, have_peer = false;  // what can be selected
+    double probe_ms[3] = {-1.0, -1.0, -1.0};    // last probe: one product's exchange by form
+    std::string rccl_why;                       // why RCCL is not available (AUTO)
+    PushTargets targets;                        // DIRECT: every rank's full vector
     std::vector<hipEvent_t> ev_pushed, ev_placed;
     std::mutex phase_mu;
     std::condition_variable phase_cv;
@@ -171,7 +210,7 @@ struct smvp_sharded {
     std::mutex mu;
     std::condition_variable cv_go, cv_done;
     unsigned long long job = 0;
-    int job_allgather = 0, job_timed = 0, pending = 0;
+    int job_allgather = 0, job_timed = 0, job_skip_products = 0, pending = 0;
     bool quit = false;
     std::vector<int> job_rc;
     std::vector<std::string> job_err;
@@ -237,9 +276,10 @@ extern "C" void smvp_shard_opts_default(smvp_shard_opts_t *o)
 {
     if (!o)
         return;
+    o->struct_size = (unsigned)sizeof *o;
     o->chunks = 0;
     o->balance = 1;
-    o->exchange = SMVP_EXCHANGE_RCCL;
+    o->exchange = SMVP_EXCHANGE_AUTO;
 }
 
 namespace {
@@ -255,14 +295,20 @@ int sharded_common(smvp_sharded *h, int ngpus, const int *devices, int rows, int
     smvp_shard_opts_t def;
     smvp_shard_opts_default(&def);
     const smvp_shard_opts_t *o = opts ? opts : &def;
-    if (o->exchange != SMVP_EXCHANGE_RCCL && o->exchange != SMVP_EXCHANGE_COPIES)
+    if (o->struct_size != (unsigned)sizeof(smvp_shard_opts_t))
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_shard_opts_t of %u bytes, this library's has %u: initialise it with "
+                                            "smvp_shard_opts_default and build against this library's header",
+                          o->struct_size, (unsigned)sizeof(smvp_shard_opts_t));
+    if (o->exchange < SMVP_EXCHANGE_RCCL || o->exchange > SMVP_EXCHANGE_AUTO)
         return smvp::fail(SMVP_ERR_INVALID, "unknown exchange %d", o->exchange);
-    const bool copies = o->exchange == SMVP_EXCHANGE_COPIES;  // ranks may share a device ("virtual ranks")
+    // the push forms, asked for by name, let ranks share a device ("virtual ranks")
+    const bool copies = o->exchange == SMVP_EXCHANGE_COPIES || o->exchange == SMVP_EXCHANGE_DIRECT;
     if (ngpus < 1 || (!copies && ngpus > visible) || ngpus > 64)
         return smvp::fail(SMVP_ERR_INVALID, "%d GPUs requested, %d visible", ngpus, visible);
     if (o->chunks < 0 || o->chunks > 64)
         return smvp::fail(SMVP_ERR_INVALID, "chunks per GPU must lie in [1, 64] (0 = default)");
-    h->exchange = o->exchange;
+    h->auto_exchange = o->exchange == SMVP_EXCHANGE_AUTO;
+    h->exchange = h->auto_exchange ? SMVP_EXCHANGE_RCCL : o->exchange;
     h->n = ngpus;
     h->chunks = o->chunks > 0 ? o->chunks : (ngpus > 1 ? 4 : 1);
     h->rows = rows, h->cols = cols, h->nnz = nnz;
@@ -347,34 +393,65 @@ int sharded_common(smvp_sharded *h, int ngpus, const int *devices, int rows, int
         HIP_TRY(hipMalloc((void **)&h->d_x[g], sizeof(double) * vec_len));
         HIP_TRY(hipMalloc((void **)&h->d_norm[g], sizeof(unsigned long long)));
         HIP_TRY(hipMalloc((void **)&h->d_y_local[g], sizeof(double) * h->loff[C]));
-        HIP_TRY(hipMalloc((void **)&h->d_wire[g], sizeof(double) * h->woff[C]));
+        if (!copies)  // the padded wire buffer is RCCL's (the push forms write straight into the full vectors)
+            HIP_TRY(hipMalloc((void **)&h->d_wire[g], sizeof(double) * h->woff[C]));
         HIP_TRY(hipMalloc((void **)&h->d_y_full[g], sizeof(double) * vec_len));
         HIP_TRY(hipMalloc((void **)&h->d_seg[g], sizeof(int4) * seg.size()));
         HIP_TRY(hipMemset(h->d_y_local[g], 0, sizeof(double) * h->loff[C]));
-        HIP_TRY(hipMemset(h->d_wire[g], 0, sizeof(double) * h->woff[C]));
+        if (!copies)
+            HIP_TRY(hipMemset(h->d_wire[g], 0, sizeof(double) * h->woff[C]));
         HIP_TRY(hipMemset(h->d_y_full[g], 0, sizeof(double) * vec_len));
         HIP_TRY(hipMemcpy(h->d_seg[g], seg.data(), sizeof(int4) * seg.size(), hipMemcpyHostToDevice));
     }
-    if (copies) {
-        // pieces travel by device-to-device copies: let every device reach its peers' buffers where they differ
-        for (size_t g = 0; g < n; ++g)
-            for (size_t r = 0; r < n; ++r)
+    for (size_t g = 0; g < n; ++g)
+        h->targets.y_full[g] = h->d_y_full[g];
+    bool distinct = true;
+    for (size_t g = 0; g < n; ++g)
+        for (size_t r = 0; r < g; ++r)
+            distinct = distinct && h->device[g] != h->device[r];
+    const int want = o->exchange;
+    // the push forms: every device must reach its peers' vectors where they differ
+    if (want != SMVP_EXCHANGE_RCCL) {
+        h->have_peer = true;
+        for (size_t g = 0; g < n && h->have_peer; ++g)
+            for (size_t r = 0; r < n && h->have_peer; ++r)
                 if (h->device[g] != h->device[r]) {
                     HIP_TRY(hipSetDevice(h->device[g]));
                     const hipError_t e = hipDeviceEnablePeerAccess(h->device[r], 0);
-                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
-                        return smvp::fail(SMVP_ERR_HIP, "device %d cannot reach device %d: %s", h->device[g], h->device[r],
-                                          hipGetErrorString(e));
                     (void)hipGetLastError();
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                        if (want != SMVP_EXCHANGE_AUTO)
+                            return smvp::fail(SMVP_ERR_HIP, "device %d cannot reach device %d: %s", h->device[g], h->device[r],
+                                              hipGetErrorString(e));
+                        h->have_peer = false;
+                    }
                 }
-        return SMVP_OK;
     }
-    if (int rc = load_rccl(&h->rccl))
-        return rc;
-    h->comm.assign(n, nullptr);
-    ncclResult_t nr = h->rccl->CommInitAll(h->comm.data(), ngpus, h->device.data());
-    if (nr != ncclSuccess)
-        return smvp::fail(SMVP_ERR_HIP, "ncclCommInitAll failed: %s", h->rccl->GetErrorString(nr));
+    // RCCL: one communicator rank per (distinct) device
+    if (want == SMVP_EXCHANGE_RCCL || (want == SMVP_EXCHANGE_AUTO && distinct)) {
+        int rc = load_rccl(&h->rccl);
+        if (rc == SMVP_OK) {
+            h->comm.assign(n, nullptr);
+            const ncclResult_t nr = h->rccl->CommInitAll(h->comm.data(), ngpus, h->device.data());
+            if (nr != ncclSuccess) {
+                rc = smvp::fail(SMVP_ERR_HIP, "ncclCommInitAll failed: %s", h->rccl->GetErrorString(nr));
+                h->comm.clear();
+            }
+        }
+        if (rc != SMVP_OK) {
+            if (want == SMVP_EXCHANGE_RCCL || !h->have_peer)
+                return rc;
+            h->rccl_why = smvp_last_error();  // AUTO goes on with the pushes
+        } else {
+            h->have_rccl = true;
+        }
+    } else if (want == SMVP_EXCHANGE_AUTO) {
+        h->rccl_why = "several ranks share a device";
+    }
+    if (!h->have_rccl && !h->have_peer)
+        return smvp::fail(SMVP_ERR_UNSUPPORTED, "no exchange is available (RCCL: %s; no peer access)", h->rccl_why.c_str());
+    if (h->auto_exchange)
+        h->exchange = h->have_rccl ? SMVP_EXCHANGE_RCCL : SMVP_EXCHANGE_DIRECT;  // until the probe has spoken
     return SMVP_OK;
 }
 
@@ -400,9 +477,11 @@ extern "C" int smvp_csr_sharded_create_ex(smvp_sharded_t **out, int ngpus, const
             std::vector<int> rp((size_t)(b - a) + 1);
             for (int r = a; r <= b; ++r)
                 rp[(size_t)(r - a)] = row_ptr[r] - row_ptr[a];
-            rc = smvp_csr_create(&h->csr[g * C + c], h->device[g], b - a, cols, row_ptr[b] - row_ptr[a], rp.data(),
-                                 col_ind + row_ptr[a], val + row_ptr[a], SMVP_MEM_HOST, nullptr);
+            rc = smvp_csr_create_block(&h->csr[g * C + c], h->device[g], b - a, cols, row_ptr[b] - row_ptr[a], rp.data(),
+                                       col_ind + row_ptr[a], val + row_ptr[a], SMVP_MEM_HOST, nullptr, a);
         }
+    if (rc == SMVP_OK && h->auto_exchange)
+        rc = smvp_sharded_probe_exchange(h, 3);
     if (rc != SMVP_OK) {
         smvp_sharded_destroy(h);
         return rc;
@@ -473,6 +552,8 @@ extern "C" int smvp_tjds_sharded_create_ex(smvp_sharded_t **out, int ngpus, cons
                                       v.data(), SMVP_MEM_HOST);
         }
     }
+    if (rc == SMVP_OK && h->auto_exchange)
+        rc = smvp_sharded_probe_exchange(h, 3);
     if (rc != SMVP_OK) {
         smvp_sharded_destroy(h);
         return rc;
@@ -569,32 +650,41 @@ void phase_give_up(smvp_sharded *h)
     h->phase_cv.notify_all();
 }
 
-int issue_product(smvp_sharded *h, size_t g, int allgather, int timed)
+int issue_product(smvp_sharded *h, size_t g, int allgather, int timed, bool skip_products)
 {
     const size_t C = (size_t)h->chunks;
     const bool overlap = allgather == SMVP_GATHER_OVERLAPPED;
     HIP_TRY(hipSetDevice(h->device[g]));
-    if (h->format == 1)
+    if (h->format == 1 && !skip_products)
         for (size_t c = 0; c < C; ++c)
             if (int rc = smvp_tjds_zero_y(h->tjds[g * C + c], h->d_y_local[g] + h->loff[c], h->stream[g]))
                 return rc;
     if (timed)
         HIP_TRY(hipEventRecord(h->ev0[g], h->stream[g]));
-    const bool copies = h->exchange == SMVP_EXCHANGE_COPIES;
+    const bool pushes = h->exchange != SMVP_EXCHANGE_RCCL;  // COPIES / DIRECT: straight into every rank's full vector
     const size_t n = (size_t)h->n;
-    bool placed_awaited[2] = {false, false};  // per stream the copies go on: [0] the compute stream, [1] the exchange stream
+    bool placed_awaited[2] = {false, false};  // per stream the pushes go on: [0] the compute stream, [1] the exchange stream
     auto gather = [&](size_t c, hipStream_t st) -> int {
-        if (copies) {  // this rank's piece of chunk c into every rank's wire buffer
+        if (pushes) {  // this rank's chunk c into rows [a, b) of every rank's full vector
             if (!placed_awaited[st == h->stream[g] ? 0 : 1]) {
-                // ... once every rank has read the previous product's pieces out of its wire buffer (ev_placed: recorded
-                // by all of them before anybody left that product, see below)
+                // ... once every rank is done with the previous product's full vector (ev_placed: recorded by all of them
+                // before anybody left that product, and again behind a feed-back's copy of it)
                 for (size_t r = 0; r < n; ++r)
                     HIP_TRY(hipStreamWaitEvent(st, h->ev_placed[r], 0));
                 placed_awaited[st == h->stream[g] ? 0 : 1] = true;
             }
-            for (size_t r = 0; r < n; ++r)
-                HIP_TRY(hipMemcpyAsync(h->d_wire[r] + h->woff[c] + g * (size_t)h->pad[c], h->d_y_local[g] + h->loff[c],
-                                       sizeof(double) * (size_t)h->pad[c], hipMemcpyDeviceToDevice, st));
+            const int a = h->cbounds[g * (C + 1) + c], b = h->cbounds[g * (C + 1) + c + 1];
+            if (b <= a)
+                return SMVP_OK;
+            const double *src = h->d_y_local[g] + h->loff[c];
+            if (h->exchange == SMVP_EXCHANGE_COPIES) {
+                for (size_t r = 0; r < n; ++r)
+                    HIP_TRY(hipMemcpyAsync(h->d_y_full[r] + a, src, sizeof(double) * (size_t)(b - a), hipMemcpyDeviceToDevice, st));
+            } else {
+                const unsigned bx = (unsigned)std::min(256, std::max(1, (b - a + 4095) / 4096));
+                hipLaunchKernelGGL(push_chunk, dim3(bx, (unsigned)n), dim3(256), 0, st, src, h->targets, (long long)a, b - a);
+                HIP_TRY(hipGetLastError());
+            }
             return SMVP_OK;
         }
         const ncclResult_t nr = h->rccl->AllGather(h->d_y_local[g] + h->loff[c], h->d_wire[g] + h->woff[c], (size_t)h->pad[c],
@@ -605,10 +695,12 @@ int issue_product(smvp_sharded *h, size_t g, int allgather, int timed)
     };
     for (size_t c = 0; c < C; ++c) {
         double *yc = h->d_y_local[g] + h->loff[c];
-        const int rc = h->format == 0 ? smvp_csr_spmv(h->csr[g * C + c], h->d_x[g], yc, h->stream[g])
-                                      : smvp_tjds_spmv(h->tjds[g * C + c], yc, h->stream[g]);
-        if (rc != SMVP_OK)
-            return rc;
+        if (!skip_products) {
+            const int rc = h->format == 0 ? smvp_csr_spmv(h->csr[g * C + c], h->d_x[g], yc, h->stream[g])
+                                          : smvp_tjds_spmv(h->tjds[g * C + c], yc, h->stream[g]);
+            if (rc != SMVP_OK)
+                return rc;
+        }
         if (overlap) {
             HIP_TRY(hipEventRecord(h->ev_chunk[g * C + c], h->stream[g]));
             HIP_TRY(hipStreamWaitEvent(h->comm_stream[g], h->ev_chunk[g * C + c], 0));
@@ -625,22 +717,19 @@ int issue_product(smvp_sharded *h, size_t g, int allgather, int timed)
             HIP_TRY(hipEventRecord(h->ev_gathered[g], h->comm_stream[g]));
             HIP_TRY(hipStreamWaitEvent(h->stream[g], h->ev_gathered[g], 0));
         }
-        if (copies) {
-            // every rank's pieces must have landed here before they are placed: each rank records "pushed" behind its
-            // own copies, the issuing threads meet (so that every event has been recorded), then each waits for all
+        if (pushes) {
+            // every rank's chunks must have landed here before this rank's product counts as done: each rank records "pushed"
+            // behind its own pushes, the issuing threads meet (so that every event has been recorded), then each waits for all
             HIP_TRY(hipEventRecord(h->ev_pushed[g], h->stream[g]));
             phase_barrier(h);
             for (size_t r = 0; r < n; ++r)
                 HIP_TRY(hipStreamWaitEvent(h->stream[g], h->ev_pushed[r], 0));
-        }
-        if (h->rows > 0) {
+            HIP_TRY(hipEventRecord(h->ev_placed[g], h->stream[g]));
+            phase_barrier(h);  // the next product's pushes wait for these events: all recorded before anybody goes on
+        } else if (h->rows > 0) {
             hipLaunchKernelGGL(place_gathered, dim3((unsigned)((h->rows + 255) / 256)), dim3(256), 0, h->stream[g], h->d_wire[g],
                                h->d_y_full[g], h->d_seg[g], h->nseg, h->rows);
             HIP_TRY(hipGetLastError());
-        }
-        if (copies) {
-            HIP_TRY(hipEventRecord(h->ev_placed[g], h->stream[g]));
-            phase_barrier(h);  // the next product's copies wait for these events: all recorded before anybody goes on
         }
     }
     if (timed)
@@ -652,16 +741,16 @@ void issuer_main(smvp_sharded *h, size_t g)
 {
     unsigned long long seen = 0;
     for (;;) {
-        int allgather, timed;
+        int allgather, timed, skip;
         {
             std::unique_lock<std::mutex> lock(h->mu);
             h->cv_go.wait(lock, [&] { return h->quit || h->job != seen; });
             if (h->quit)
                 return;
             seen = h->job;
-            allgather = h->job_allgather, timed = h->job_timed;
+            allgather = h->job_allgather, timed = h->job_timed, skip = h->job_skip_products;
         }
-        const int rc = issue_product(h, g, allgather, timed);
+        const int rc = issue_product(h, g, allgather, timed, skip != 0);
         if (rc != SMVP_OK)
             phase_give_up(h);  // (exchange by copies) the peers must not wait for this rank at the meeting points
         {
@@ -676,13 +765,11 @@ void issuer_main(smvp_sharded *h, size_t g)
 
 }  // namespace
 
-// One product, asynchronous (see issue_product); returns when every GPU's launches and collectives are enqueued.
-extern "C" int smvp_sharded_spmv(smvp_sharded_t *h, int allgather, int timed)
+namespace {
+
+// One job on every rank: a product (or, skip_products, only its exchange) enqueued by the ranks' issuing threads.
+int run_job(smvp_sharded *h, int allgather, int timed, bool skip_products)
 {
-    if (!h || allgather < 0 || allgather > SMVP_GATHER_AFTER)
-        return smvp::fail(SMVP_ERR_INVALID, "smvp_sharded_spmv: bad argument");
-    if (h->broken)
-        return smvp::fail(SMVP_ERR_HIP, "the sharded handle is unusable after a failed product (%s): destroy it", h->broken_why.c_str());
     const size_t n = (size_t)h->n;
     static const bool always_threads = [] {
         const char *e = getenv("SMVP_SHARDED_THREADS");  // development switch: the issuing threads with one GPU too
@@ -690,7 +777,7 @@ extern "C" int smvp_sharded_spmv(smvp_sharded_t *h, int allgather, int timed)
     }();
     if (n == 1 && !always_threads) {
         DeviceScope keep;
-        const int rc = issue_product(h, 0, allgather, timed);
+        const int rc = issue_product(h, 0, allgather, timed, skip_products);
         if (rc != SMVP_OK && allgather) {
             h->broken = true;
             h->broken_why = smvp_last_error();
@@ -705,7 +792,7 @@ extern "C" int smvp_sharded_spmv(smvp_sharded_t *h, int allgather, int timed)
     }
     {
         std::unique_lock<std::mutex> lock(h->mu);
-        h->job_allgather = allgather, h->job_timed = timed;
+        h->job_allgather = allgather, h->job_timed = timed, h->job_skip_products = skip_products ? 1 : 0;
         h->pending = (int)n;
         ++h->job;
         h->cv_go.notify_all();
@@ -720,6 +807,100 @@ extern "C" int smvp_sharded_spmv(smvp_sharded_t *h, int allgather, int timed)
             h->broken_why = "GPU " + std::to_string(h->device[g]) + ": " + h->job_err[g];
             return smvp::fail(h->job_rc[g], "GPU %d: %s", h->device[g], h->job_err[g].c_str());
         }
+    return SMVP_OK;
+}
+
+bool exchange_available(const smvp_sharded *h, int e)
+{
+    return e == SMVP_EXCHANGE_RCCL ? h->have_rccl : (e == SMVP_EXCHANGE_COPIES || e == SMVP_EXCHANGE_DIRECT) ? h->have_peer : false;
+}
+
+}  // namespace
+
+// One product, asynchronous (see issue_product); returns when every GPU's launches and collectives are enqueued.
+extern "C" int smvp_sharded_spmv(smvp_sharded_t *h, int allgather, int timed)
+{
+    if (!h || allgather < 0 || allgather > SMVP_GATHER_AFTER)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_sharded_spmv: bad argument");
+    if (h->broken)
+        return smvp::fail(SMVP_ERR_HIP, "the sharded handle is unusable after a failed product (%s): destroy it", h->broken_why.c_str());
+    return run_job(h, allgather, timed, false);
+}
+
+// The exchange of one product's y -- every chunk of every rank, nothing to overlap with -- under every available form,
+// `reps` timed runs behind one untimed; a handle created with SMVP_EXCHANGE_AUTO then keeps the fastest.  What travels is
+// whatever y_local holds (zeros right after creation): the bytes and the calls are those of a product.
+extern "C" int smvp_sharded_probe_exchange(smvp_sharded_t *h, int reps)
+{
+    if (!h || reps < 1 || reps > 1000)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_sharded_probe_exchange: bad argument");
+    if (h->broken)
+        return smvp::fail(SMVP_ERR_HIP, "the sharded handle is unusable after a failed product (%s): destroy it", h->broken_why.c_str());
+    const int before = h->exchange;
+    int best = -1;
+    for (int e = SMVP_EXCHANGE_RCCL; e <= SMVP_EXCHANGE_DIRECT; ++e) {
+        h->probe_ms[e] = -1.0;
+        if (!exchange_available(h, e))
+            continue;
+        h->exchange = e;
+        double sum = 0.0;
+        for (int i = 0; i <= reps; ++i) {
+            int rc = run_job(h, SMVP_GATHER_AFTER, 1, true);
+            double ms = 0.0;
+            if (rc == SMVP_OK)
+                rc = smvp_sharded_synchronize(h, &ms);
+            if (rc != SMVP_OK) {
+                h->exchange = before;
+                return rc;
+            }
+            if (i > 0)
+                sum += ms;
+        }
+        h->probe_ms[e] = sum / reps;
+        if (best < 0 || h->probe_ms[e] < h->probe_ms[best])
+            best = e;
+    }
+    h->exchange = h->auto_exchange && best >= 0 ? best : before;
+    return SMVP_OK;
+}
+
+extern "C" int smvp_sharded_exchange_info(const smvp_sharded_t *h, int *active, int *available, double *ms, int *rccl_ranks)
+{
+    if (!h)
+        return smvp::fail(SMVP_ERR_INVALID, "null handle");
+    if (active)
+        *active = h->exchange;
+    if (available)
+        *available = (h->have_rccl ? 1 << SMVP_EXCHANGE_RCCL : 0) |
+                     (h->have_peer ? (1 << SMVP_EXCHANGE_COPIES) | (1 << SMVP_EXCHANGE_DIRECT) : 0);
+    if (ms)
+        for (int e = 0; e < 3; ++e)
+            ms[e] = h->probe_ms[e];
+    if (rccl_ranks) {
+        *rccl_ranks = 0;
+        if (h->have_rccl && !h->comm.empty() && h->comm[0]) {
+            int count = 0;
+            if (h->rccl->CommCount && h->rccl->CommCount(h->comm[0], &count) == ncclSuccess)
+                *rccl_ranks = count;
+            else
+                *rccl_ranks = (int)h->comm.size();
+        }
+    }
+    return SMVP_OK;
+}
+
+extern "C" int smvp_sharded_set_exchange(smvp_sharded_t *h, int exchange)
+{
+    if (!h || exchange < SMVP_EXCHANGE_RCCL || exchange > SMVP_EXCHANGE_DIRECT)
+        return smvp::fail(SMVP_ERR_INVALID, "smvp_sharded_set_exchange: one of RCCL, COPIES, DIRECT");
+    if (!exchange_available(h, exchange))
+        return smvp::fail(SMVP_ERR_UNSUPPORTED, "exchange %d is not available on this handle%s%s", exchange,
+                          exchange == SMVP_EXCHANGE_RCCL && !h->rccl_why.empty() ? ": " : "",
+                          exchange == SMVP_EXCHANGE_RCCL ? h->rccl_why.c_str() : "");
+    // products in flight were enqueued under the old form: let them finish before the next one is issued differently
+    if (int rc = smvp_sharded_synchronize(h, nullptr))
+        return rc;
+    h->exchange = exchange;
     return SMVP_OK;
 }
 
@@ -738,6 +919,8 @@ extern "C" int smvp_sharded_feed_back(smvp_sharded_t *h, int normalize)
             HIP_TRY(smvp::launch_normalize_max(h->d_y_full[g], h->rows, h->d_norm[g], h->stream[g]));
         HIP_TRY(hipMemcpyAsync(h->d_x[g], h->d_y_full[g], sizeof(double) * (size_t)h->rows, hipMemcpyDeviceToDevice,
                                h->stream[g]));
+        // the push forms write the next product's chunks straight into the full vectors: not before this copy has read them
+        HIP_TRY(hipEventRecord(h->ev_placed[g], h->stream[g]));
         if (int rc = set_operand_everywhere(h, g))
             return rc;
     }

@@ -34,7 +34,7 @@ class TimeStats(C.Structure):
 
 
 class RunOpts(C.Structure):
-    _fields_ = [("device", C.c_int), ("csr_kernel", C.c_int), ("csr_param", C.c_int),
+    _fields_ = [("struct_size", C.c_uint), ("device", C.c_int), ("csr_kernel", C.c_int), ("csr_param", C.c_int),
                 ("tjds_ref_quirks", C.c_int), ("convert_on_device", C.c_int), ("ngpus", C.c_int),
                 ("iterate", C.c_int), ("normalize", C.c_int), ("tjds_mode", C.c_int), ("timing", C.c_int),
                 ("shard_exchange", C.c_int), ("x", C.c_void_p)]
@@ -49,11 +49,12 @@ class RunInfo(C.Structure):
 
 
 class ShardOpts(C.Structure):
-    _fields_ = [("chunks", C.c_int), ("balance", C.c_int), ("exchange", C.c_int)]
+    _fields_ = [("struct_size", C.c_uint), ("chunks", C.c_int), ("balance", C.c_int), ("exchange", C.c_int)]
 
 
 GATHER_NONE, GATHER_OVERLAPPED, GATHER_AFTER = 0, 1, 2
-EXCHANGE_RCCL, EXCHANGE_COPIES = 0, 1
+EXCHANGE_RCCL, EXCHANGE_COPIES, EXCHANGE_DIRECT, EXCHANGE_AUTO = 0, 1, 2, 3
+EXCHANGE_NAMES = {EXCHANGE_RCCL: "rccl", EXCHANGE_COPIES: "copies", EXCHANGE_DIRECT: "direct", EXCHANGE_AUTO: "auto"}
 
 
 class SmvpError(RuntimeError):
@@ -73,12 +74,12 @@ EXPORTS = [
     "smvp_cache_write_csr", "smvp_cache_read_header", "smvp_cache_read_csr", "smvp_coo_from_csr",
     "smvp_csr_from_coo", "smvp_tjds_from_coo", "smvp_csr_from_coo_device", "smvp_tjds_from_coo_device",
     "smvp_device_count", "smvp_device_info", "smvp_csr_plan_info", "smvp_tjds_plan_info",
-    "smvp_csr_create", "smvp_csr_set_kernel", "smvp_csr_get_kernel", "smvp_csr_gather_spread", "smvp_csr_spmv",
+    "smvp_csr_create", "smvp_csr_create_block", "smvp_csr_far_share", "smvp_csr_set_kernel", "smvp_csr_get_kernel", "smvp_csr_gather_spread", "smvp_csr_spmv",
     "smvp_csr_describe", "smvp_csr_plan_launches", "smvp_csr_destroy",
     "smvp_tjds_create", "smvp_tjds_set_x", "smvp_tjds_zero_y", "smvp_tjds_spmv",
     "smvp_tjds_set_ref_quirks", "smvp_tjds_set_mode", "smvp_tjds_set_tile", "smvp_tjds_set_value_cache", "smvp_tjds_get_value_cache", "smvp_tjds_describe", "smvp_tjds_destroy",
     "smvp_shard_opts_default", "smvp_csr_sharded_create", "smvp_csr_sharded_create_ex", "smvp_tjds_sharded_create",
-    "smvp_tjds_sharded_create_ex", "smvp_sharded_layout", "smvp_sharded_set_csr_kernel", "smvp_sharded_set_x", "smvp_sharded_spmv",
+    "smvp_tjds_sharded_create_ex", "smvp_sharded_layout", "smvp_sharded_set_csr_kernel", "smvp_sharded_probe_exchange", "smvp_sharded_exchange_info", "smvp_sharded_set_exchange", "smvp_sharded_set_x", "smvp_sharded_spmv",
     "smvp_sharded_synchronize", "smvp_sharded_feed_back", "smvp_sharded_get_y", "smvp_sharded_info", "smvp_sharded_destroy",
     "smvp_run_opts_default", "smvp_csr_compute", "smvp_tjds_compute", "smvp_last_run_info",
     "smvp_time_stats", "smvp_generate_report_text", "smvp_cisr_coegen", "smvp_cisr_coegen_path",
@@ -98,6 +99,8 @@ def lib():
         L.smvp_version_string.restype = C.c_char_p
         vp, ci = C.c_void_p, C.c_int
         L.smvp_csr_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, vp, vp, vp, ci, vp]
+        L.smvp_csr_create_block.argtypes = [C.POINTER(vp), ci, ci, ci, ci, vp, vp, vp, ci, vp, C.c_longlong]
+        L.smvp_csr_far_share.argtypes = [vp, C.POINTER(C.c_double)]
         L.smvp_csr_set_kernel.argtypes = [vp, ci, ci]
         L.smvp_csr_get_kernel.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
         L.smvp_csr_gather_spread.argtypes = [vp, C.POINTER(C.c_double)]
@@ -131,6 +134,9 @@ def lib():
         L.smvp_shard_opts_default.restype = None
         L.smvp_sharded_layout.argtypes = [vp, C.POINTER(ci), vp, vp]
         L.smvp_sharded_set_csr_kernel.argtypes = [vp, ci, ci]
+        L.smvp_sharded_probe_exchange.argtypes = [vp, ci]
+        L.smvp_sharded_exchange_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), vp, C.POINTER(ci)]
+        L.smvp_sharded_set_exchange.argtypes = [vp, ci]
         L.smvp_sharded_set_x.argtypes = [vp, vp]
         L.smvp_sharded_spmv.argtypes = [vp, ci, ci]
         L.smvp_sharded_synchronize.argtypes = [vp, C.POINTER(C.c_double)]
@@ -399,22 +405,23 @@ def _stream_ptr(stream):
 class CsrMatrix:
     """Device-resident CSR matrix (smvp_csr_t).  Arrays may be numpy (copied to HBM) or torch CUDA tensors (adopted)."""
 
-    def __init__(self, rows, cols, row_ptr, col_ind, val, device=0):
+    def __init__(self, rows, cols, row_ptr, col_ind, val, device=0, first_row=0):
+        """first_row: global number of the first row when this is a row block of a larger matrix (smvp_csr_create_block)."""
         self.rows, self.cols = rows, cols
         self._h = C.c_void_p()
         self._keep = None
         if isinstance(row_ptr, np.ndarray):
             rp, ci, v = _arr(row_ptr, np.int32), _arr(col_ind, np.int32), _arr(val, np.float64)
             self.nnz = int(rp[rows]) if rows >= 0 else 0
-            _check(lib().smvp_csr_create(C.byref(self._h), device, rows, cols, self.nnz, _p(rp), _p(ci), _p(v),
-                                         MEM_HOST, None), "smvp_csr_create")
+            _check(lib().smvp_csr_create_block(C.byref(self._h), device, rows, cols, self.nnz, _p(rp), _p(ci), _p(v),
+                                               MEM_HOST, None, int(first_row)), "smvp_csr_create_block")
         else:
             host_rp = _arr(row_ptr.cpu().numpy(), np.int32)
             self.nnz = int(host_rp[rows])
             self._keep = (row_ptr, col_ind, val)
-            _check(lib().smvp_csr_create(C.byref(self._h), device, rows, cols, self.nnz, _dev_ptr(row_ptr),
-                                         _dev_ptr(col_ind), _dev_ptr(val), MEM_DEVICE, _p(host_rp)),
-                   "smvp_csr_create")
+            _check(lib().smvp_csr_create_block(C.byref(self._h), device, rows, cols, self.nnz, _dev_ptr(row_ptr),
+                                               _dev_ptr(col_ind), _dev_ptr(val), MEM_DEVICE, _p(host_rp), int(first_row)),
+                   "smvp_csr_create_block")
 
     def set_kernel(self, kernel, param=0):
         _check(lib().smvp_csr_set_kernel(self._h, kernel, param), "smvp_csr_set_kernel")
@@ -435,6 +442,12 @@ class CsrMatrix:
         i = PlanInfo()
         _check(lib().smvp_csr_plan_info(self._h, C.byref(i)), "smvp_csr_plan_info")
         return {"matrix_bytes": i.matrix_bytes, "plan_bytes": i.plan_bytes, "build_ms": i.build_ms}
+
+    def far_share(self):
+        """Share of the entries further than 4096 from the diagonal of the whole matrix (AUTO's choice of the binned plan); -1: not measured."""
+        v = C.c_double()
+        _check(lib().smvp_csr_far_share(self._h, C.byref(v)), "smvp_csr_far_share")
+        return v.value
 
     def gather_spread(self):
         """Share of the gathers that pull their own line of x (what AUTO's choice of the column sweep rests on); -1: not sampled."""
@@ -537,7 +550,7 @@ class TjdsMatrix:
 class ShardedMatrix:
     """Row blocks of one matrix on several GPUs of this process (smvp_sharded_t), RCCL all-gather of y."""
 
-    def __init__(self, fmt, ngpus, rows, cols, coo=None, csr=None, devices=None, chunks=0, balance=True, exchange=EXCHANGE_RCCL):
+    def __init__(self, fmt, ngpus, rows, cols, coo=None, csr=None, devices=None, chunks=0, balance=True, exchange=EXCHANGE_AUTO):
         self._h = C.c_void_p()
         devs = None if devices is None else (C.c_int * ngpus)(*devices)
         o = ShardOpts()
@@ -567,6 +580,23 @@ class ShardedMatrix:
 
     def set_csr_kernel(self, kernel, param=0):
         _check(lib().smvp_sharded_set_csr_kernel(self._h, kernel, param), "smvp_sharded_set_csr_kernel")
+
+    def probe_exchange(self, reps=3):
+        """Time one product's exchange of y under every available form (AUTO handles then keep the fastest)."""
+        _check(lib().smvp_sharded_probe_exchange(self._h, int(reps)), "smvp_sharded_probe_exchange")
+        return self.exchange_info()
+
+    def exchange_info(self):
+        """{"active": EXCHANGE_*, "available": [EXCHANGE_*...], "ms": {name: ms of the last probe}, "rccl_ranks": n}."""
+        act, av, rk = C.c_int(), C.c_int(), C.c_int()
+        ms = (C.c_double * 3)()
+        _check(lib().smvp_sharded_exchange_info(self._h, C.byref(act), C.byref(av), ms, C.byref(rk)), "smvp_sharded_exchange_info")
+        return {"active": act.value, "active_name": EXCHANGE_NAMES[act.value],
+                "available": [e for e in range(3) if av.value >> e & 1],
+                "ms": {EXCHANGE_NAMES[e]: ms[e] for e in range(3) if ms[e] >= 0}, "rccl_ranks": rk.value}
+
+    def set_exchange(self, exchange):
+        _check(lib().smvp_sharded_set_exchange(self._h, int(exchange)), "smvp_sharded_set_exchange")
 
     def set_x(self, x=None):
         keep = None if x is None else _arr(x, np.float64)
@@ -608,7 +638,7 @@ class ShardedMatrix:
 
 # ------------------------------------------------- reference-shaped entry points
 def _run_opts(device, csr_kernel, csr_param, ref_quirks, x, device_convert=False, ngpus=0, iterate=False,
-              normalize=False, tjds_mode=TJDS_MODE_AUTO, timing=TIMING_AUTO, exchange=EXCHANGE_RCCL):
+              normalize=False, tjds_mode=TJDS_MODE_AUTO, timing=TIMING_AUTO, exchange=EXCHANGE_AUTO):
     o = RunOpts()
     lib().smvp_run_opts_default(C.byref(o))
     o.device, o.csr_kernel, o.csr_param, o.tjds_ref_quirks = device, csr_kernel, csr_param, int(ref_quirks)
@@ -630,7 +660,7 @@ def last_run_info():
 
 
 def csr_compute(coo, rows, cols, iters=1, device=0, kernel=CSR_KERNEL_AUTO, param=0, x=None, device_convert=False,
-                ngpus=0, iterate=False, normalize=False, timing=TIMING_AUTO, exchange=EXCHANGE_RCCL):
+                ngpus=0, iterate=False, normalize=False, timing=TIMING_AUTO, exchange=EXCHANGE_AUTO):
     """smvp_csr_compute: COO in, (y, per-iteration ms, TimeStats) out."""
     nnz = len(coo)
     coo = _arr(coo, COO_DTYPE)
@@ -644,7 +674,7 @@ def csr_compute(coo, rows, cols, iters=1, device=0, kernel=CSR_KERNEL_AUTO, para
 
 
 def tjds_compute(coo, rows, cols, iters=1, device=0, ref_quirks=False, x=None, device_convert=False, ngpus=0,
-                 iterate=False, normalize=False, mode=TJDS_MODE_AUTO, timing=TIMING_AUTO, exchange=EXCHANGE_RCCL):
+                 iterate=False, normalize=False, mode=TJDS_MODE_AUTO, timing=TIMING_AUTO, exchange=EXCHANGE_AUTO):
     """smvp_tjds_compute: COO in, (y, per-iteration ms, TimeStats) out."""
     nnz = len(coo)
     coo = _arr(coo, COO_DTYPE)

@@ -83,3 +83,95 @@ def test_c_layer_child_is_given_up_on_when_it_hangs(tmp_path, monkeypatch):
     assert "error" in out and "3" in out["error"]
     out = child("import json\nprint(json.dumps({'n_gpus': 8, 'chunks_1': {'overlapped': {'event_ms': 1.0}}}))\n")
     assert out["n_gpus"] == 8 and "child process of rank 0" in out["ran_in"] and out["chunks_1"]["overlapped"]["event_ms"] == 1.0
+
+
+def test_plain_invocation_with_gpus_2_starts_its_own_ranks(monkeypatch, capsys):
+    """`python bench.py --gpus 2` without torch.distributed.run around it (the driver's command shape) must not exit 1
+    with "needs one process per GPU": the parent -- before torch or HIP are touched -- starts one child per rank with the
+    rendezvous environment set, relays rank 0's JSON line and returns the children's worst exit code."""
+    import io
+    import subprocess
+
+    started = []
+
+    class Child:
+        def __init__(self, cmd, env=None, stdout=None, **kw):
+            started.append((cmd, env, kw))
+            self.rank = int(env["RANK"])
+            self.pid = 10 ** 7 + self.rank          # no such process group: end() must cope
+            self.returncode = None
+            self.stdout = io.StringIO('{"n_gpus": 2, "value": 1.0}\n') if stdout == subprocess.PIPE else None
+
+        def poll(self):
+            self.returncode = 0 if self.rank == 0 else rc_other[0]
+            return self.returncode
+
+        def wait(self, timeout=None):
+            return self.poll()
+
+        def kill(self):
+            pass
+
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(subprocess, "Popen", Child)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    rc_other = [0]
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    assert len(started) == 2
+    for rank, (cmd, env, kw) in enumerate(started):
+        assert cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "2", "--steps", "3"]
+        assert env["RANK"] == env["LOCAL_RANK"] == str(rank) and env["WORLD_SIZE"] == "2" and env["MASTER_ADDR"] == "127.0.0.1"
+        assert int(env["MASTER_PORT"]) > 0 and kw.get("start_new_session") is True
+    assert started[0][1]["MASTER_PORT"] == started[1][1]["MASTER_PORT"]
+    assert capsys.readouterr().out.count('{"n_gpus": 2') == 1
+    # a rank that fails: its exit code comes out
+    started.clear()
+    rc_other[0] = 3
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 3
+
+
+def test_self_launched_ranks_really_run(tmp_path):
+    """The same end to end on this CPU-only box: both ranks start, find no GPU, say so, and the launcher returns non-zero
+    quickly with nothing left running."""
+    import os
+    import subprocess
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(bench.__file__), "bench.py"), "--gpus", "2", "--no-c-layer",
+                        "--no-config4", "--copies", "2", "--steps", "1"], capture_output=True, text=True, env=env, timeout=300)
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("a GPU is present: the gpu-marked test covers the real run")
+    assert p.returncode != 0 and "needs one process per GPU" not in p.stderr
+    assert p.stderr.count("bench.py needs a GPU") == 2 and "starting 2 rank processes" in p.stderr
+    assert time.time() - t0 < 120
+
+
+def test_flat_keys_are_scalars_and_complete():
+    """roofline's flat keys: what the driver's parse keeps (it drops nested objects)."""
+    roof = {}
+    others = {"tjds": {"frac": 0.5, "ms_per_product": 0.4, "traffic_over_algorithmic": 1.44, "moved_frac_of_peak": 0.7},
+              "config4": {"frac": 0.22, "ms_per_product": 2.2, "t1_ms": 2.2, "tN_step_ms": 0.6, "tN_step_after_ms": 0.7,
+                          "tN_products_only_ms": 0.4, "speedup_overlapped": 3.6, "speedup_after": 3.1, "speedup_products_only": 5.5,
+                          "chunks_chosen": 2, "eighth_of_n8": {"chosen": 4, "inputs": {"product_ms_by_chunks": {"1": 0.41, "2": 0.5, "4": 0.54}}}},
+              "config4_c_layer": {"chunks_1": {"overlapped": {"event_ms": 2.3}, "products_only": {"event_ms": 2.2}},
+                                  "exchange_rccl_ms": 0.1, "exchange_direct_ms": 0.05, "exchange_chosen": "direct", "rccl_ranks": 8},
+              "sample_matrices_us_per_product": {"memplus.mtx": {"csr_avg_ms": 3.1, "tjds_loop_wall_ms_per_product": 6.0}, "note": "x"}}
+    extra = {"tjds_two_phase": {"frac_of_hbm_peak": 0.25}, "config5_pwt": {"csr_ms_per_step": 0.0037}}
+    bench.flat_keys(roof, others, extra, 8, {"backend": "nccl (RCCL)", "rccl_ranks": 8, "exchange": "e" * 300, "self_launched": True})
+    assert all(not isinstance(v, (dict, list)) for v in roof.values())
+    assert roof["frac_tjds"] == 0.5 and roof["traffic_over_alg_tjds"] == 1.44 and roof["frac_tjds_colmajor"] == 0.25
+    assert roof["config4_speedup_overlapped"] == 3.6 and roof["config4_chunks_chosen"] == 2 and roof["config4_eighth_ms_1chunk"] == 0.41
+    assert roof["config4_c_layer_overlapped_ms_1chunk"] == 2.3 and roof["exchange_direct_ms"] == 0.05 and roof["c_layer_rccl_ranks"] == 8
+    assert roof["memplus_csr_us"] == 3.1 and roof["config5_csr_us"] == 3.7 and roof["rccl_ranks"] == 8 and roof["n_gpus"] == 8

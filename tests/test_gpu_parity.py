@@ -262,6 +262,57 @@ def test_colsweep_rows_that_meet_in_a_chunk(torch):
         assert np.array_equal(y, ref)
 
 
+def test_binned_plan_on_a_row_block_of_a_sharded_matrix(torch):
+    """A rank's row block [r0, r1) of the SURVEY 8(d) random model, as smvp_sharded.hip and bench.py create it
+    (smvp_csr_create_block, first_row = r0): the diagonal lies at column r0 + local row, so the near / far split, the far
+    share AUTO decides on and K6's windows of x are those of the whole matrix.  The same arrays created WITHOUT the offset
+    -- what round 4 did at N > 1 -- look all far: every entry takes the 28-byte far path and K6 loads windows nothing points
+    into.  Both give the right product; only the first is the plan that was measured at N = 1."""
+    rows = 1 << 21
+    r0, r1 = rows // 2, rows
+    row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_MEMPLUS_SHAPED, 12345, rows, rows, 0, r0, r1)
+    n_loc = r1 - r0
+    x = sm.vector_random(rows)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+    scale = row_scale(row_ptr, col_ind, val, x)
+    rows_of = np.repeat(np.arange(r0, r1), np.diff(row_ptr))
+    far_true = float((np.abs(col_ind.astype(np.int64) - rows_of) > 4096).mean())
+    dx = dev(torch, x)
+    A = sm.CsrMatrix(n_loc, rows, row_ptr, col_ind, val, first_row=r0)
+    assert abs(A.far_share() - far_true) < 1e-6 and 0.3 < far_true < 0.5
+    assert A.get_kernel() == (sm.CSR_KERNEL_BINNED, 4096) and A.describe()[0].startswith("csr_binned: csr_near_window + ")
+    B = sm.CsrMatrix(n_loc, rows, row_ptr, col_ind, val)          # no offset: the band around the (true) diagonal counts as far
+    assert B.far_share() > 0.95
+    B.set_kernel(sm.CSR_KERNEL_BINNED, 0)
+    for M in (A, B):
+        dy = torch.full((n_loc,), float("nan"), dtype=torch.float64, device="cuda")
+        M.spmv(dx, dy)
+        torch.cuda.synchronize()
+        assert_close(dy.cpu().numpy(), ref, scale)
+    # the split is the whole matrix's: 20 B per far entry + 10 B per near slot -- the all-far plan is much larger
+    assert A.plan_info()["plan_bytes"] < 0.8 * B.plan_info()["plan_bytes"]
+    # the tile kernel's near engine and another band on the offset handle
+    A.set_kernel(sm.CSR_KERNEL_BINNED, 512)
+    dy = torch.full((n_loc,), float("nan"), dtype=torch.float64, device="cuda")
+    A.spmv(dx, dy)
+    torch.cuda.synchronize()
+    assert_close(dy.cpu().numpy(), ref, scale)
+    A.close()
+    B.close()
+    # the sharded layer passes every chunk's first row on: 2 and 3 virtual ranks x 2 chunks on the whole model, binned by choice
+    full = sm.synth_csr(sm.SYNTH_MEMPLUS_SHAPED, 12345, rows, rows)
+    ref_full = ob.csr_spmv(full[0], full[1], full[2], x)
+    scale_full = row_scale(full[0], full[1], full[2], x)
+    for ranks in (2, 3):
+        S = sm.ShardedMatrix("csr", ranks, rows, rows, csr=full, devices=[0] * ranks, chunks=2, exchange=sm.EXCHANGE_DIRECT)
+        S.set_csr_kernel(sm.CSR_KERNEL_BINNED, 0)
+        S.set_x(x)
+        S.spmv(allgather=sm.GATHER_OVERLAPPED)
+        S.synchronize()
+        assert_close(S.get_y(ranks - 1, gathered=True), ref_full, scale_full)
+        S.close()
+
+
 @pytest.mark.parametrize("near", ["window", "tile"])
 def test_binned_plan_on_the_random_model(torch, monkeypatch, near):
     """SURVEY 8(d)'s memplus-shaped random model (2^22 rows here): AUTO picks the binned plan -- near part with a row
@@ -1154,6 +1205,51 @@ def test_bench_script_runs_small(torch):
     assert rm["bit_identical_run_to_run"] and rm["plan"]["plan_bytes"] >= 0 and rm["launches_per_product"] >= 1
     assert "plan" in o["tjds"] and o["tjds"]["convert_device_ms"] > 0 and "plan" in o["pwt_tiled_csr"] and "plan" in o["pwt_tiled_tjds"]
     assert "csr_vs_reference_report" not in lines[0]      # no GPU-over-reference ratio on the in-kernel clock any more
+    # round 5: the driver's parse keeps only the SCALAR keys of `roofline` -- everything a record needs is there flat
+    r = j["roofline"]
+    for key in ("frac_tjds", "frac_tjds_colmajor", "frac_survey_random_model", "frac_config4", "frac_pwt_csr", "frac_pwt_tjds",
+                "ms_tjds", "ms_survey_random_model", "ms_config4",
+                "config4_t1_ms", "config4_tN_step_ms", "config4_tN_step_after_ms", "config4_tN_products_only_ms",
+                "config4_speedup_overlapped", "config4_speedup_after", "config4_speedup_products_only", "config4_chunks_chosen",
+                "config4_eighth_ms_1chunk", "config4_eighth_ms_2chunk", "config4_eighth_ms_4chunk",
+                "config4_c_layer_products_only_ms_1chunk", "config4_c_layer_overlapped_ms_1chunk", "config4_c_layer_after_ms_4chunk",
+                "exchange_rccl_ms", "exchange_copies_ms", "exchange_direct_ms", "c_layer_exchange_chosen",
+                "memplus_csr_us", "memplus_tjds_us", "memplus_csr_loop_wall_us", "pwt_csr_us", "config5_csr_us", "config5_both_us",
+                "exchange", "dist_backend", "rccl_ranks", "n_gpus", "self_launched"):
+        assert key in r and not isinstance(r[key], (dict, list)), key
+    assert r["frac_tjds"] == o["tjds"]["frac"] and r["frac_config4"] == o["config4"]["frac"] and r["rccl_ranks"] == 0
+    assert r["config4_t1_ms"] == o["config4"]["t1_ms"] and r["config4_speedup_overlapped"] == 1.0 and r["self_launched"] is False
+
+
+def test_bench_starts_its_own_ranks(torch):
+    """`python bench.py --gpus 2` with no launcher around it (the driver's command shape): the script starts its two ranks
+    itself -- here over gloo, sharing the one GPU -- relays rank 0's JSON line and leaves no process behind."""
+    import json
+    import sys
+
+    import psutil
+    from conftest import ROOT
+
+    env = dict(os.environ, SMVP_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    before = {q.pid for q in psutil.process_iter()}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--copies", "8", "--rows", "300000",
+                        "--steps", "3", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    r = j["roofline"]
+    assert j["n_gpus"] == 2 and r["n_gpus"] == 2 and r["self_launched"] is True and r["dist_backend"] == "gloo" and r["rccl_ranks"] == 0
+    assert j["extra"]["dist"]["ranks_in_group"] == 2
+    for key in ("config4_t1_ms", "config4_tN_step_ms", "config4_tN_products_only_ms", "config4_speedup_overlapped",
+                "config4_speedup_after", "config4_chunks_chosen", "headline_products_only_ms", "exchange"):
+        assert key in r, key
+    assert "config4_c_layer_error" not in r, r.get("config4_c_layer_error")
+    assert r["config4_c_layer_overlapped_ms_1chunk"] > 0 and r["exchange_direct_ms"] > 0
+    left = [q for q in psutil.process_iter(["cmdline"]) if q.pid not in before and "bench.py" in " ".join(q.info["cmdline"] or [])]
+    assert not left, left
 
 
 # --------------------------------------------------- device-side format conversion
@@ -1374,14 +1470,18 @@ def test_sharded_unequal_blocks_on_several_gpus(torch, ngpus):
             assert np.array_equal(got[sm.GATHER_OVERLAPPED], got[sm.GATHER_AFTER])    # the same bits either way
 
 
+@pytest.mark.parametrize("push", ["copies", "direct"])
 @pytest.mark.parametrize("ranks", [2, 4, 8])
-def test_sharded_virtual_ranks_on_one_gpu(torch, ranks):
-    """The N-GPU code of the C layer with N ranks sharing this box's one GPU (SMVP_EXCHANGE_COPIES: the all-gather as
-    device-to-device copies between the issuing threads): rows % N != 0, more ranks than rows, empty chunks, every rank's
-    gathered y against the oracle, both exchange forms bit-equal, CSR and TJDS, several products back to back (the wire
-    buffers are reused), power iteration, the column sweep on zero-row chunks, an early destroy."""
+def test_sharded_virtual_ranks_on_one_gpu(torch, ranks, push):
+    """The N-GPU code of the C layer with N ranks sharing this box's one GPU (SMVP_EXCHANGE_COPIES / _DIRECT: every rank
+    pushes its chunks straight into every rank's full vector, by hipMemcpyAsync or by one kernel per chunk, ordered by events
+    and a meeting point of the issuing threads): rows % N != 0, more ranks than rows, empty chunks, every rank's
+    gathered y against the oracle, both gather modes bit-equal, CSR and TJDS, several products back to back (the full
+    vectors are written again), power iteration, the column sweep on zero-row chunks, an early destroy."""
     rng = np.random.default_rng(100 + ranks)
     devices = [0] * ranks
+    PUSH = sm.EXCHANGE_COPIES if push == "copies" else sm.EXCHANGE_DIRECT
+    OTHER = sm.EXCHANGE_DIRECT if push == "copies" else sm.EXCHANGE_COPIES
     for rows, cols, chunks in ((1003, 997, 3), (max(1, ranks - 1), 5, 2), (257, 257, 1)):
         lens = [min(int(l), cols) for l in rng.integers(0, 9, rows)]
         row_ptr, col_ind, val = csr_from_lengths(rng, lens, cols)
@@ -1393,7 +1493,7 @@ def test_sharded_virtual_ranks_on_one_gpu(torch, ranks):
             got = {}
             for gather in (sm.GATHER_OVERLAPPED, sm.GATHER_AFTER):
                 S = sm.ShardedMatrix(fmt, ranks, rows, cols, coo=coo, csr=(row_ptr, col_ind, val), devices=devices, chunks=chunks,
-                                     exchange=sm.EXCHANGE_COPIES)
+                                     exchange=PUSH)
                 n, tallest = S.info()
                 c, bounds, cb = S.layout()
                 assert n == ranks and c == chunks and bounds[0] == 0 and bounds[-1] == rows and np.all(np.diff(bounds) >= 0)
@@ -1405,6 +1505,18 @@ def test_sharded_virtual_ranks_on_one_gpu(torch, ranks):
                     assert_close(S.get_y(slot, gathered=True), ref, scale)
                 assert_close(S.get_y(0, gathered=False), ref, scale)
                 got[gather] = S.get_y(ranks - 1, gathered=True)
+                info = S.exchange_info()
+                assert info["active"] == PUSH and set(info["available"]) == {sm.EXCHANGE_COPIES, sm.EXCHANGE_DIRECT} and info["rccl_ranks"] == 0
+                if gather == sm.GATHER_OVERLAPPED:       # the other push form on the same handle: the same bits
+                    S.set_exchange(OTHER)
+                    S.spmv(allgather=gather)
+                    S.synchronize()
+                    assert np.array_equal(S.get_y(0, gathered=True), got[gather])
+                    with pytest.raises(sm.SmvpError):
+                        S.set_exchange(sm.EXCHANGE_RCCL)     # ranks share a device: no communicator
+                    S.set_exchange(PUSH)
+                    probe = S.probe_exchange(2)              # both forms timed; an explicitly chosen form stays
+                    assert probe["active"] == PUSH and probe["ms"]["copies"] > 0 and probe["ms"]["direct"] > 0 and "rccl" not in probe["ms"]
                 if fmt == "csr" and gather == sm.GATHER_AFTER:
                     S.set_csr_kernel(sm.CSR_KERNEL_COLSWEEP, 1024)      # zero-row chunks included
                     S.spmv(allgather=gather)
@@ -1415,7 +1527,7 @@ def test_sharded_virtual_ranks_on_one_gpu(torch, ranks):
     # power iteration: the gathered y is the next operand on every rank
     m, n, coo = load("ibm32.mtx")
     row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
-    S = sm.ShardedMatrix("csr", ranks, m, n, csr=(row_ptr, col_ind, val), devices=devices, chunks=2, exchange=sm.EXCHANGE_COPIES)
+    S = sm.ShardedMatrix("csr", ranks, m, n, csr=(row_ptr, col_ind, val), devices=devices, chunks=2, exchange=PUSH)
     S.set_x(None)
     v = np.ones(n)
     for _ in range(4):
@@ -1426,17 +1538,59 @@ def test_sharded_virtual_ranks_on_one_gpu(torch, ranks):
     assert np.array_equal(S.get_y(ranks - 1, gathered=True), v)        # pattern matrix: exact
     S.close()
     # early destroy with work in flight; and through the reference-shaped entry points
-    S = sm.ShardedMatrix("tjds", ranks, m, n, coo=coo, devices=devices, exchange=sm.EXCHANGE_COPIES)
+    S = sm.ShardedMatrix("tjds", ranks, m, n, coo=coo, devices=devices, exchange=PUSH)
     S.set_x(None)
     S.spmv(allgather=sm.GATHER_OVERLAPPED)
     S.close()
-    y1, ms, st = sm.csr_compute(coo, m, n, iters=5, ngpus=ranks, exchange=sm.EXCHANGE_COPIES)
-    y2, _, _ = sm.tjds_compute(coo, m, n, iters=5, ngpus=ranks, exchange=sm.EXCHANGE_COPIES)
+    y1, ms, st = sm.csr_compute(coo, m, n, iters=5, ngpus=ranks, exchange=PUSH)
+    y2, _, _ = sm.tjds_compute(coo, m, n, iters=5, ngpus=ranks, exchange=PUSH)
     want = ob.csr_spmv(row_ptr, col_ind, val, np.ones(n))
     assert np.array_equal(y1, want) and np.array_equal(y2, want) and len(ms) == 5 and st.time_min > 0
-    # RCCL cannot put two ranks on one device: refused, not hung
+    # RCCL cannot put two ranks on one device, and AUTO does not guess that virtual ranks are wanted: refused, not hung
+    for ex in (sm.EXCHANGE_RCCL, sm.EXCHANGE_AUTO):
+        with pytest.raises(sm.SmvpError):
+            sm.ShardedMatrix("csr", 2, m, n, csr=(row_ptr, col_ind, val), devices=[0, 0], exchange=ex)
+
+
+def test_sharded_exchange_auto_is_a_measured_choice(torch):
+    """SMVP_EXCHANGE_AUTO (the default): every available form -- RCCL, peer copies, the push kernel -- moves one product's
+    y when the handle is created, the fastest is kept, the times are reported, and every form gives the same bits
+    (one GPU here: the choice itself only means something on eight)."""
+    m, n, coo = load("memplus.mtx")
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, np.ones(n))
+    S = sm.ShardedMatrix("csr", 1, m, n, csr=(row_ptr, col_ind, val), chunks=3)      # exchange: AUTO
+    info = S.exchange_info()
+    assert set(info["available"]) == {sm.EXCHANGE_RCCL, sm.EXCHANGE_COPIES, sm.EXCHANGE_DIRECT} and info["rccl_ranks"] == 1
+    assert set(info["ms"]) == {"rccl", "copies", "direct"} and all(v > 0 for v in info["ms"].values())
+    assert info["ms"][info["active_name"]] == min(info["ms"].values())
+    S.set_x(None)
+    got = {}
+    for ex in (sm.EXCHANGE_RCCL, sm.EXCHANGE_COPIES, sm.EXCHANGE_DIRECT):
+        S.set_exchange(ex)
+        for gather in (sm.GATHER_OVERLAPPED, sm.GATHER_AFTER):
+            S.spmv(allgather=gather)
+            S.synchronize()
+            got[ex, gather] = S.get_y(0, gathered=True)
+    first = got[sm.EXCHANGE_RCCL, sm.GATHER_OVERLAPPED]
+    assert np.allclose(first, ref, rtol=1e-12, atol=1e-12) and all(np.array_equal(first, g) for g in got.values())
     with pytest.raises(sm.SmvpError):
-        sm.ShardedMatrix("csr", 2, m, n, csr=(row_ptr, col_ind, val), devices=[0, 0])
+        S.set_exchange(sm.EXCHANGE_AUTO)
+    S.close()
+    # a caller built against another layout of the options struct is refused, not misread
+    import ctypes as C
+    o = sm.ShardOpts()
+    sm.lib().smvp_shard_opts_default(C.byref(o))
+    assert o.struct_size == C.sizeof(sm.ShardOpts) and o.exchange == sm.EXCHANGE_AUTO
+    o.struct_size -= 4
+    h = C.c_void_p()
+    rc = sm.lib().smvp_csr_sharded_create_ex(C.byref(h), 1, None, m, n, len(coo), row_ptr.ctypes.data_as(C.c_void_p),
+                                             col_ind.ctypes.data_as(C.c_void_p), val.ctypes.data_as(C.c_void_p), C.byref(o))
+    assert rc != 0 and b"smvp_shard_opts_default" in sm.lib().smvp_last_error()
+    ro = sm.RunOpts()                      # never passed through smvp_run_opts_default
+    y = np.zeros(m)
+    rc = sm.lib().smvp_csr_compute(coo.ctypes.data_as(C.c_void_p), m, n, len(coo), 1, C.byref(ro), y.ctypes.data_as(C.c_void_p), None, None)
+    assert rc != 0 and b"smvp_run_opts_default" in sm.lib().smvp_last_error()
 
 
 def test_cli_virtual_gpus(torch, tmp_path):
