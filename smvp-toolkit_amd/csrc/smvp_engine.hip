@@ -210,6 +210,24 @@ void free_sweep_plan(smvp_csr *h)
 // fill, 8192 rows run at 1.0, 4096 at 0.86, 2048 at 0.80 of the rate (config 4: 2.25 / 2.62 ms); the height is the one with
 // the best fill x rate, never so short that a pass moves the window by more than ~1.3 MB (tools/exp_colsweep.py,
 // profiles/r03_colsweep_measured.txt).
+// Round 5: the height need not be a power of two.  With generations of at most 256 workgroups the heights 8192 / 4096 / 2048
+// leave a rank's block of BASELINE config 4 (1.25 M rows) either 40 % of the CUs idle (153 workgroups of 8192 rows) or three
+// generations -- and every generation makes each of the eight L2s pull all of x again (8 x 80 MB: 1.9 GB for 0.56 GB of the
+// block's own entries).  Candidates are now also the heights that cut the rows into EXACTLY g x 256
+// workgroups, g = 1, 2, ...: 1.25 M rows as 256 workgroups of 4884 rows are one full generation.  The rate of a height in
+// between is read off the measured ones on a log scale.
+double sweep_rate(int rb)
+{
+    const struct { double lg, rate; } pts[] = {{10.0, 0.70}, {11.0, 0.80}, {12.0, 0.86}, {13.0, 1.0}};
+    const double lg = std::log2((double)std::max(rb, 1));
+    if (lg <= pts[0].lg)
+        return pts[0].rate * std::max(0.25, lg / pts[0].lg);
+    for (int i = 0; i < 3; ++i)
+        if (lg <= pts[i + 1].lg)
+            return pts[i].rate + (pts[i + 1].rate - pts[i].rate) * (lg - pts[i].lg) / (pts[i + 1].lg - pts[i].lg);
+    return pts[3].rate;
+}
+
 void choose_sweep_shape(int rows, int cols, int nnz, int want_rb, int *rb, int *per_launch)
 {
     const double mean = rows > 0 ? std::max(1.0, (double)nnz / rows) : 1.0;
@@ -217,17 +235,30 @@ void choose_sweep_shape(int rows, int cols, int nnz, int want_rb, int *rb, int *
     while (floor_rb < 8192 && (double)floor_rb * mean * 160.0 < (double)cols)
         floor_rb <<= 1;
     auto generations = [](int nrb) { return (nrb + 255) / 256; };
+    std::vector<int> heights;
+    for (int hgt : {8192, 4096, 2048, 1024})
+        if (hgt >= floor_rb)
+            heights.push_back(hgt);
+    // ... and the heights of whole generations; those may be half as tall as the floor (a full chip outweighs the faster window:
+    // a 312 K-row chunk of config 4 as 256 x 1224 rows 0.0975 ms, as 153 x 2048 rows 0.134; profiles/r05_colsweep_heights.txt)
+    for (int g = 1; g <= 16 && rows > 0; ++g) {
+        const long long want = ((long long)rows + 256ll * g - 1) / (256ll * g);  // rows per workgroup for g full generations
+        const int h4 = (int)std::min<long long>(8192, (want + 3) / 4 * 4);      // four strips per workgroup
+        if (h4 >= std::max(1024, floor_rb / 2))
+            heights.push_back(h4);
+    }
     int r = floor_rb;
     double best = -1.0;
-    const struct { int rows; double rate; } heights[] = {{8192, 1.0}, {4096, 0.86}, {2048, 0.80}, {1024, 0.70}};
-    for (const auto &hgt : heights) {
-        if (hgt.rows < floor_rb)
-            continue;
-        const int nrb = (rows + hgt.rows - 1) / hgt.rows;
-        const double fill = (double)nrb / (std::max(1, generations(nrb)) * 256.0);
-        if (fill * hgt.rate > best) {
-            best = fill * hgt.rate;
-            r = hgt.rows;
+    int best_gen = 1 << 30;
+    for (int hgt : heights) {
+        const int nrb = (rows + hgt - 1) / hgt;
+        const int gen = std::max(1, generations(nrb));
+        const double score = (double)nrb / (gen * 256.0) * sweep_rate(hgt);
+        // (a tie within 1 % goes to fewer generations: each costs 8 x the operand in L2 fills)
+        if (score > best * 1.01 || (score > best * 0.99 && gen < best_gen)) {
+            best = std::max(best, score);
+            best_gen = gen;
+            r = hgt;
         }
     }
     if (want_rb > 0)
@@ -508,7 +539,7 @@ bool choose_csr_kernel(smvp_csr *h, int kernel, int param)
         return false;
     if (kernel == SMVP_CSR_KERNEL_STREAM_CARRY && param != 0 && param != 1024 && param != 2048)
         return false;
-    if (kernel == SMVP_CSR_KERNEL_COLSWEEP && param != 0 && param != 1024 && param != 2048 && param != 4096 && param != 8192)
+    if (kernel == SMVP_CSR_KERNEL_COLSWEEP && param != 0 && (param < 256 || param > 8192 || param % 4 != 0))
         return false;
     if (kernel == SMVP_CSR_KERNEL_BINNED && param < 0)
         return false;
@@ -724,7 +755,7 @@ extern "C" int smvp_csr_set_kernel(smvp_csr_t *h, int kernel, int param)
     DeviceScope on(h->device);
     if (!choose_csr_kernel(h, kernel, param))
         return smvp::fail(SMVP_ERR_INVALID, "entries per tile must be 256 (stream only), 1024 or 2048 for the kernel "
-                                            "this matrix resolves to (column sweep: 1024 ... 8192 rows per block; binned: the near band, >= 0)");
+                                            "this matrix resolves to (column sweep: 256 ... 8192 rows per block, a multiple of 4; binned: the near band, >= 0)");
     const double t0 = wall_ms();
     free_sweep_plan(h);
     free_binned(h);

@@ -1228,16 +1228,18 @@ __global__ __launch_bounds__(kSweepBlock) void csr_colsweep(
         __builtin_nontemporal_store(sums[i], &y[r0 + i]);
 }
 
-// Chunks in flight per wavefront.  Strips of 2048 rows leave room for two workgroups per CU (64 KB of sums each):
-// two chunks in flight make up for the missing wavefronts (config 4: 2.25 against 2.55 ms; one rank's eighth
-// 0.44 against 0.50); shorter strips run more wavefronts per CU and do best with one (0.134 / 0.144 / 0.160 ms
-// for 1 / 2 / 4 on a 312 K-row chunk).  SMVP_SWEEP_G=1|2|4 overrides (development switch).  Asked once per plan build (the
-// engine keeps the answer in the handle), never on a launch path.
+// Chunks in flight per wavefront.  A launch generation is one workgroup per CU (four wavefronts): with tall strips two chunks
+// in flight make up for the missing wavefronts, with short ones they only make the window race (the strips' streams are
+// short).  Measured (MI355X, config 4's columns; ms for G = 1 / 2; profiles/r05_colsweep_heights.txt): strips of 2048 rows
+// 2.55 / 2.25 (10 M rows), 0.497 / 0.444 (1.25 M rows); 1221 rows 0.315 / 0.287 (1.25 M), 0.632 / 0.575 (2.5 M); 814 rows
+// 0.648 / 0.636; 611 rows 0.328 / 0.373; 512 rows 0.413 / 0.468; 407 rows 0.348 / 0.459 -- two from about 800 rows on.
+// SMVP_SWEEP_G=1|2|4 overrides (development switch).  Asked once per plan build (the engine keeps the answer in the
+// handle), never on a launch path.
 int sweep_chunks_in_flight(int strip_rows)
 {
     const char *env = getenv("SMVP_SWEEP_G");
     const int env_g = env ? atoi(env) : 0;
-    return env_g == 1 || env_g == 2 || env_g == 4 ? env_g : (strip_rows >= 2048 ? 2 : 1);
+    return env_g == 1 || env_g == 2 || env_g == 4 ? env_g : (strip_rows >= 768 ? 2 : 1);
 }
 
 hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, const double *e_val, const unsigned short *e_row,

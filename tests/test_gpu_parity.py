@@ -210,7 +210,7 @@ def test_colsweep_on_scattered_columns(torch):
     x = np.random.default_rng(9).random(cols)
     ref = ob.csr_spmv(row_ptr, col_ind, val, x)
     A = sm.CsrMatrix(rows, cols, row_ptr, col_ind, val)
-    assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, 1024)      # 700 K rows: 684 workgroups of 1024 rows = 3 generations of 228
+    assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, 2736)      # 700 K rows: 256 workgroups of 2736 rows = ONE full generation (round 5)
     dx = dev(torch, x)
     dy = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
     A.spmv(dx, dy)
@@ -221,7 +221,7 @@ def test_colsweep_on_scattered_columns(torch):
     A.spmv(dx, dy)
     torch.cuda.synchronize()
     assert np.array_equal(dy.cpu().numpy(), ref)                  # 32 entries per row: the tile kernel is serial too
-    for rb, want in ((0, 1024), (8192, 8192), (2048, 2048), (4096, 4096)):
+    for rb, want in ((0, 2736), (8192, 8192), (2048, 2048), (4096, 4096), (1024, 1024), (3000, 3000), (1028, 1028), (256, 256)):
         A.set_kernel(sm.CSR_KERNEL_COLSWEEP, rb)
         assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, want) and A.describe()[0].startswith("csr_colsweep<")
         for _ in range(2):
@@ -230,9 +230,11 @@ def test_colsweep_on_scattered_columns(torch):
             torch.cuda.synchronize()
             assert np.array_equal(dy.cpu().numpy(), ref)
     with pytest.raises(sm.SmvpError):
-        A.set_kernel(sm.CSR_KERNEL_COLSWEEP, 3000)
+        A.set_kernel(sm.CSR_KERNEL_COLSWEEP, 3001)            # four strips per workgroup: a multiple of 4
+    with pytest.raises(sm.SmvpError):
+        A.set_kernel(sm.CSR_KERNEL_COLSWEEP, 8196)
     A.set_kernel(sm.CSR_KERNEL_AUTO, 0)                       # AUTO again: the sweep, plan rebuilt
-    assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, 1024)
+    assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, 2736)
     dy.fill_(float("nan"))
     A.spmv(dx, dy)
     torch.cuda.synchronize()
@@ -1593,6 +1595,85 @@ def test_sharded_exchange_auto_is_a_measured_choice(torch):
     assert rc != 0 and b"smvp_run_opts_default" in sm.lib().smvp_last_error()
 
 
+@pytest.mark.parametrize("chunks", [1, 4])
+def test_sharded_eight_virtual_ranks_at_config4_scale(torch, chunks):
+    """BASELINE config 4's shape at half its size -- 5 M x 5 M, 32 uniform entries per row, seed 2024 -- over EIGHT virtual
+    ranks (the N = 8 code of the C layer on this box's one GPU), 1 and 4 chunks per rank: AUTO gives every chunk the
+    column sweep (its own plan over all of x, zero-padded `woff` / chunk bounds at 10^5-row scale), both gather modes and
+    both push forms give the same bits on every rank, y equals the row sums of val on ALL rows (x = ones) and the oracle
+    on a row sample (x random)."""
+    rows, ranks = 5_000_000, 8
+    rp, ci, v = sm.synth_csr(sm.SYNTH_UNIFORM, 2024, rows, rows, 32, 0, rows, threads=16)
+    assert int(rp[-1]) == 32 * rows
+    S = sm.ShardedMatrix("csr", ranks, rows, rows, csr=(rp, ci, v), devices=[0] * ranks, chunks=chunks, exchange=sm.EXCHANGE_DIRECT)
+    c, bounds, cb = S.layout()
+    assert c == chunks and np.all(np.abs(np.diff(bounds) - rows // ranks) <= 1) and cb[-1][-1] == rows
+    # x = ones (the reference's operand): every row's sum of val, all rows, every rank's copy
+    host = np.add.reduceat(v, rp[:-1])
+    scale = np.add.reduceat(np.abs(v), rp[:-1])
+    S.set_x(None)
+    got = {}
+    for ex in (sm.EXCHANGE_DIRECT, sm.EXCHANGE_COPIES):
+        S.set_exchange(ex)
+        for gather in (sm.GATHER_OVERLAPPED, sm.GATHER_AFTER):
+            S.spmv(allgather=gather)
+            S.synchronize()
+            got[ex, gather] = S.get_y(ranks - 1, gathered=True)
+    first = got[sm.EXCHANGE_DIRECT, sm.GATHER_OVERLAPPED]
+    assert np.all(np.abs(first - host) <= TOL * scale)
+    assert all(np.array_equal(first, g) for g in got.values())
+    for slot in (0, 3):
+        assert np.array_equal(S.get_y(slot, gathered=True), first)
+    assert np.array_equal(S.get_y(0, gathered=False), first)              # the slices as the ranks hold them
+    # a general operand: the oracle on samples of rows at the seams between ranks and chunks
+    x = sm.vector_random(rows)
+    S.set_x(x)
+    S.spmv(allgather=sm.GATHER_OVERLAPPED)
+    S.synchronize()
+    y = S.get_y(5, gathered=True)
+    for a in (0, int(cb[0][1]) - 2000 if chunks > 1 else 300_000, int(bounds[1]) - 2000, int(bounds[7]) - 2000, rows - 4000):
+        a = max(0, a)
+        b = min(rows, a + 4000)
+        ref = ob.csr_spmv((rp[a:b + 1] - rp[a]).astype(np.int32), ci[rp[a]:rp[b]], v[rp[a]:rp[b]], x)
+        sc = ob.csr_spmv((rp[a:b + 1] - rp[a]).astype(np.int32), ci[rp[a]:rp[b]], np.abs(v[rp[a]:rp[b]]), np.abs(x))
+        assert np.array_equal(y[a:b], ref) or np.all(np.abs(y[a:b] - ref) <= TOL * sc)
+        # 32 entries per row, ascending columns: the sweep and the tile kernel both sum in serial order -- the oracle's bits
+        assert np.array_equal(y[a:b], ref)
+    S.close()
+    # what AUTO gave a chunk of this size: the column sweep
+    a, b = int(cb[2][0]), int(cb[2][1])
+    A = sm.CsrMatrix(b - a, rows, (rp[a:b + 1] - rp[a]).astype(np.int32), ci[rp[a]:rp[b]], v[rp[a]:rp[b]], first_row=a)
+    assert A.get_kernel()[0] == sm.CSR_KERNEL_COLSWEEP
+    A.close()
+
+
+def test_sharded_eight_virtual_ranks_config5_pwt(torch):
+    """BASELINE config 5 over eight virtual ranks: pwt.mtx as stored, CSR then TJDS back to back, row blocks balanced by
+    entries; every rank's gathered y equals the reference's committed report, both formats, both push forms."""
+    m, n, coo = load("pwt.mtx")
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    want = np.array([float(t) for t in ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_%s.txt" % REPORTS["pwt.mtx"][0]))])
+    ranks = 8
+    for ex in (sm.EXCHANGE_DIRECT, sm.EXCHANGE_COPIES):
+        C_ = sm.ShardedMatrix("csr", ranks, m, n, csr=(row_ptr, col_ind, val), devices=[0] * ranks, chunks=2, exchange=ex)
+        T_ = sm.ShardedMatrix("tjds", ranks, m, n, coo=coo, devices=[0] * ranks, chunks=2, exchange=ex)
+        C_.set_x(None)
+        T_.set_x(None)
+        for _ in range(3):                  # CSR then TJDS, back to back
+            C_.spmv(allgather=sm.GATHER_OVERLAPPED)
+            T_.spmv(allgather=sm.GATHER_OVERLAPPED)
+        C_.synchronize()
+        T_.synchronize()
+        for slot in (0, 4, 7):
+            assert np.array_equal(C_.get_y(slot, gathered=True), want)
+            assert np.array_equal(T_.get_y(slot, gathered=True), want)
+        _, bounds, _ = C_.layout()
+        cost = 12.0 * np.diff(row_ptr[bounds]) + 20.0 * np.diff(bounds)   # smvp_partition_rows: algorithmic bytes, 12 per entry + 20 per row
+        assert cost.max() - cost.min() <= 2 * (12.0 * np.diff(row_ptr).max() + 20.0)
+        C_.close()
+        T_.close()
+
+
 def test_cli_virtual_gpus(torch, tmp_path):
     """--gpus 4 --virtual-gpus on the one-GPU box: the reports equal the committed ones."""
     out = tmp_path / "virt"
@@ -1929,7 +2010,7 @@ def test_config4_full_size_properties(torch):
     row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_UNIFORM, 2024, M, M, param=32)
     assert len(col_ind) == 320_000_000
     A = sm.CsrMatrix(M, M, row_ptr, col_ind, val)
-    assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, 8192)
+    assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, 7816)      # 1280 workgroups = five FULL generations of 256 (round 5; 8192: 5 x 245)
     ones = torch.ones(M, dtype=torch.float64, device="cuda")
     y1, y2, ya, yb, yab = (torch.empty(M, dtype=torch.float64, device="cuda") for _ in range(5))
     A.spmv(ones, y1)
