@@ -1249,7 +1249,10 @@ def main():
                 e = {"rows": m, "nnz": len(coo), "iters": 1000,
                      "timing": "per product on the device: every wave stamps the constant-rate wall clock when it starts "
                                "and when its last store is acknowledged, time = max(last) - min(first); the 1000 "
-                               "products are replayed from a hipGraph" if info_c.timing == sm.TIMING_DEVICE else "hipEvent pairs",
+                               "products run %s" % ("up to 1024 per launch of the repeating kernel (barrier between products)"
+                                                     if info_c.repeat_launches else "one launch each, replayed from a hipGraph")
+                               if info_c.timing == sm.TIMING_DEVICE else "hipEvent pairs",
+                     "repeat_launches": info_c.repeat_launches, "graph_replays": info_c.graph_replays,
                      "csr_avg_ms": round(st_c.time_avg, 6), "csr_min_ms": round(st_c.time_min, 6),
                      "csr_GFLOPs": round(2.0 * len(coo) / st_c.time_avg * 1e-6, 2),
                      "csr_loop_wall_ms_per_product": round(info_c.wall_ms / 1000.0, 6),

@@ -389,8 +389,10 @@ void smvp_run_opts_default(smvp_run_opts_t *o);
 
 /* How the per-product window of main-cli.c:408-419 is taken.  EVENTS: a hipEvent pair around each product's
  * launches.  DEVICE: the kernel times itself -- every wave notes the device's constant-rate wall clock when it
- * starts and when its last store has been acknowledged; the product's time is max(last) - min(first) -- and the
- * products are replayed from a hipGraph.  AUTO picks DEVICE for launches of up to 4096 workgroups of the tile
+ * starts and when its last store has been acknowledged; the product's time is max(last) - min(first) -- and up to 1024
+ * products run as ONE launch of a repeating form of the kernel whose workgroups stay resident and meet at a (fence-free: the
+ * products are independent) barrier between two products; where that form is not available (or gives up: the grid must be
+ * resident as a whole) the products are replayed one launch each from a hipGraph.  AUTO picks DEVICE for launches of up to 4096 workgroups of the tile
  * kernels (where an event pair would measure mostly itself: the reference's own sample matrices), else EVENTS. */
 enum { SMVP_TIMING_AUTO = 0, SMVP_TIMING_EVENTS = 1, SMVP_TIMING_DEVICE = 2 };
 typedef struct smvp_run_info {
@@ -398,6 +400,9 @@ typedef struct smvp_run_info {
     int graph_replays;     /* hipGraph launches it took (0 = plain launches) */
     double wall_ms;        /* host wall time of the whole timed loop, launches, timing and waits included */
     double device_clock_khz; /* DEVICE: rate of the clock the times were taken with */
+    int repeat_launches;   /* DEVICE: launches of the repeating kernel it took -- up to 1024 products per launch, every product's
+                              window stamped between device-side barriers (0: one launch per product) */
+    int reserved;
 } smvp_run_info_t;
 int smvp_last_run_info(smvp_run_info_t *out);
 

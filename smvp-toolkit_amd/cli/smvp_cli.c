@@ -148,7 +148,7 @@ static void print_rates(const char *alg, int rows, int cols, int nnz, int diags,
                t->time_avg, flops / t->time_avg * 1e-6, bytes / t->time_avg * 1e-6);
     /* How the window of main-cli.c:408-419 was taken.  The reference's clock brackets the product call on the host; here
      * three figures exist and all are printed: the in-kernel window (what the report file's times are when the kernel
-     * times itself: launch and dispatch excluded), the host wall of the whole loop per product (capture, replays and
+     * times itself: launch and dispatch excluded), the host wall of the whole loop per product (launches, barriers and
      * read-back included), and -- with --timing events -- a hipEvent pair around every launch (which for launches of a
      * few microseconds measures mostly the events).  rocprofv3 reads 4.8 us per dispatch for the sample matrices'
      * kernels inside the graph replay (profiles/r03_cli_n1000.txt). */
@@ -156,8 +156,9 @@ static void print_rates(const char *alg, int rows, int cols, int nnz, int diags,
     if (smvp_last_run_info(&info) == SMVP_OK && info.wall_ms > 0.0) {
         printf(CYAN "[DATA]\t%s timing: " RESET "%s; whole loop %g ms of host wall time\n", alg,
                info.timing == SMVP_TIMING_DEVICE
-                   ? (info.graph_replays ? "per product on the device (wall-clock stamps in the kernel), products replayed from a hipGraph"
-                                         : "per product on the device (wall-clock stamps in the kernel)")
+                   ? (info.repeat_launches ? "per product on the device (wall-clock stamps in the kernel), up to 1024 products per launch of the repeating kernel"
+                      : info.graph_replays ? "per product on the device (wall-clock stamps in the kernel), products replayed from a hipGraph"
+                                           : "per product on the device (wall-clock stamps in the kernel)")
                    : "hipEvent pair around each product",
                info.wall_ms);
         printf(CYAN "[DATA]\t%s per product: " RESET "%.3f us %s (the times in the report file), %.3f us host wall per product over the loop\n",

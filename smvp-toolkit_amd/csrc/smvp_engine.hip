@@ -811,6 +811,46 @@ extern "C" int smvp_csr_gather_spread(smvp_csr_t *h, double *spread)
     return SMVP_OK;
 }
 
+static void fill_owner_launch(const smvp_csr_t *h, const double *d_x, double *d_y, unsigned long long *stamps, smvp::OwnerLaunch *out)
+{
+    smvp::OwnerLaunch &l = *out;
+    l.row_ptr = h->d_row_ptr, l.col_ind = h->d_col_ind, l.val = h->d_val, l.x = d_x, l.y = d_y;
+    l.tile_row = h->d_tile_row, l.tile_next = h->d_tile_next;
+    l.pos = h->d_pos, l.start_pos = h->d_start_pos;
+    if (h->flavor == smvp::kFlavorTjdsS || h->flavor == smvp::kFlavorTjdsH) {
+        l.pos = h->d_pos_sorted, l.col_ind = h->d_meta;
+        l.ovf_ptr = h->d_ovf_ptr, l.ovf_pos = h->d_ovf_pos, l.ovf_k = h->d_ovf_k;
+        l.cache_ptr = h->d_cache_ptr, l.val_cache = h->d_val_cache;
+        l.meta16 = h->d_meta16, l.group_run = h->d_group_run, l.run_ptr = h->d_run_ptr, l.run_sp = h->d_run_sp;
+    }
+    l.stamps = stamps;
+    l.rows = h->rows, l.nnz = h->nnz, l.ntiles = h->ntiles;
+    l.col16 = h->d_col16, l.col_base = h->d_col_base;
+}
+
+// `reps` products of the tile kernel in ONE launch, each product's window stamped (csr_stream_owner_repeat); grid from
+// csr_repeat_grid.  The products are those of csr_spmv_impl, bit for bit: the same kernel body walks the same tiles.
+static int csr_repeat_grid(const smvp_csr_t *h)
+{
+    if (!h || h->kernel != SMVP_CSR_KERNEL_STREAM || !h->d_tile_row || h->rows <= 0)
+        return 0;
+    DeviceScope on(h->device);
+    return smvp::owner_repeat_grid(h->vpt, h->d_col16 ? smvp::kFlavorCsr16 : h->flavor, h->ntiles);
+}
+
+static int csr_spmv_repeat(smvp_csr_t *h, const double *d_x, double *d_y, void *stream, unsigned long long *stamps, int reps, int grid,
+                           unsigned *ctl_words)
+{
+    DeviceScope on(h->device);
+    smvp::OwnerLaunch l;
+    fill_owner_launch(h, d_x, d_y, stamps, &l);
+    const hipError_t e = smvp::launch_csr_stream_owner_repeat(h->vpt, h->d_col16 ? smvp::kFlavorCsr16 : h->flavor, l, reps, grid, ctl_words,
+                                                              (hipStream_t)stream);
+    if (e != hipSuccess)
+        return smvp::fail(SMVP_ERR_HIP, "repeating CSR launch failed: %s", hipGetErrorString(e));
+    return SMVP_OK;
+}
+
 // stamps: device-side timing slots of this launch (owner kernel only), or nullptr
 static int csr_spmv_impl(smvp_csr_t *h, const double *d_x, double *d_y, void *stream, unsigned long long *stamps)
 {
@@ -879,18 +919,7 @@ static int csr_spmv_impl(smvp_csr_t *h, const double *d_x, double *d_y, void *st
         e = smvp::launch_csr_vector(h->lanes_per_row, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y, h->rows, st);
     else if (h->kernel == SMVP_CSR_KERNEL_STREAM) {
         smvp::OwnerLaunch l;
-        l.row_ptr = h->d_row_ptr, l.col_ind = h->d_col_ind, l.val = h->d_val, l.x = d_x, l.y = d_y;
-        l.tile_row = h->d_tile_row, l.tile_next = h->d_tile_next;
-        l.pos = h->d_pos, l.start_pos = h->d_start_pos;
-        if (h->flavor == smvp::kFlavorTjdsS || h->flavor == smvp::kFlavorTjdsH) {
-            l.pos = h->d_pos_sorted, l.col_ind = h->d_meta;
-            l.ovf_ptr = h->d_ovf_ptr, l.ovf_pos = h->d_ovf_pos, l.ovf_k = h->d_ovf_k;
-            l.cache_ptr = h->d_cache_ptr, l.val_cache = h->d_val_cache;
-            l.meta16 = h->d_meta16, l.group_run = h->d_group_run, l.run_ptr = h->d_run_ptr, l.run_sp = h->d_run_sp;
-        }
-        l.stamps = stamps;
-        l.rows = h->rows, l.nnz = h->nnz, l.ntiles = h->ntiles;
-        l.col16 = h->d_col16, l.col_base = h->d_col_base;
+        fill_owner_launch(h, d_x, d_y, stamps, &l);
         e = smvp::launch_csr_stream_owner(h->vpt, h->d_col16 ? smvp::kFlavorCsr16 : h->flavor, l, st);
     } else
         e = smvp::launch_csr_stream(h->vpt, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y, h->d_tile_row,
@@ -1580,7 +1609,7 @@ int check_iterate(const smvp_run_opts_t *o, int rows, int cols)
     return SMVP_OK;
 }
 
-thread_local smvp_run_info_t g_last_run = {SMVP_TIMING_EVENTS, 0, 0.0, 0.0};
+thread_local smvp_run_info_t g_last_run = {SMVP_TIMING_EVENTS, 0, 0.0, 0.0, 0, 0};
 
 double host_ms()
 {
@@ -1601,6 +1630,7 @@ constexpr int kStampMaxSlots = 16384;  // waves per launch up to which the kerne
 
 struct StampTimer {
     unsigned long long *d_stamps = nullptr, *d_first_last = nullptr;
+    unsigned *d_ctl = nullptr;  // the repeating launch's barrier counters
     hipGraphExec_t exec = nullptr;
     int exec_n = 0;
     ~StampTimer()
@@ -1611,13 +1641,18 @@ struct StampTimer {
             (void)hipFree(d_stamps);
         if (d_first_last)
             (void)hipFree(d_first_last);
+        if (d_ctl)
+            (void)hipFree(d_ctl);
     }
 };
 
 // `iters` products on s.stream, each timed on its own.  pre(y): work the reference keeps outside its window (clearing
 // y); product(x, y, stamps): the launches of one product.  stamp_slots > 0: the product can time itself on the device.
-template <class Pre, class Product>
-int run_timed_products(RunScratch &s, int rows, int iters, const smvp_run_opts_t *o, int stamp_slots, Pre pre, Product product)
+// repeat_grid > 0: the product has a repeating form -- repeat(x, y, stamps, reps, grid, ctl_words) enqueues `reps` products as
+// ONE launch that stamps every product's window (needs no `pre`); used for device-timed runs unless SMVP_NO_PERSIST is set.
+template <class Pre, class Product, class Repeat>
+int run_timed_products(RunScratch &s, int rows, int iters, const smvp_run_opts_t *o, int stamp_slots, Pre pre, Product product,
+                       int repeat_grid, Repeat repeat)
 {
     double *xc = s.d_x, *yc = s.d_y;
     const bool stamped = o->timing != SMVP_TIMING_EVENTS && !o->iterate && stamp_slots > 0 &&
@@ -1626,15 +1661,67 @@ int run_timed_products(RunScratch &s, int rows, int iters, const smvp_run_opts_t
         return smvp::fail(SMVP_ERR_UNSUPPORTED, "device-side timing needs the tile kernel of one GPU and no --iterate");
     g_last_run.timing = stamped ? SMVP_TIMING_DEVICE : SMVP_TIMING_EVENTS;
     g_last_run.graph_replays = 0;
+    g_last_run.repeat_launches = 0;
     HIP_TRY(hipStreamSynchronize(s.stream));
     const double t0 = host_ms();
+    bool repeated = false;
+    int khz = 0;
     if (stamped) {
-        int dev = 0, khz = 0;
+        int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
         if (khz <= 0)
             return smvp::fail(SMVP_ERR_HIP, "the device reports no wall-clock rate");
         g_last_run.device_clock_khz = khz;
+    }
+    if (stamped && repeat_grid > 0 && getenv("SMVP_NO_PERSIST") == nullptr) {  // (development switch: read at the start of a run)
+        // Up to kRepeatRing products per launch of the repeating kernel, the launches of a run enqueued one behind the other:
+        // every launch's windows are reduced on the device into first_last[product] and its give-up word is set aside; the
+        // host waits once per kRepeatSuper products.  A launch that gave up at one of its barriers (the grid was not resident
+        // as a whole: another process on the device) sends the whole run to the single launches below.
+        constexpr int kRepeatRing = 1024, kRepeatSuper = 1 << 20;
+        StampTimer st;
+        unsigned *d_tops = nullptr;
+        const int slots = repeat_grid * (smvp::kStreamBlock / 64);
+        const size_t per_product = (size_t)slots * 2;
+        int ring = std::min(iters, kRepeatRing);
+        while (ring > 64 && sizeof(unsigned long long) * per_product * (size_t)ring > (64u << 20))
+            ring /= 2;  // (stamps of one launch: at most 64 MB)
+        const int super = std::min(iters, kRepeatSuper), launches_per_super = (super + ring - 1) / ring;
+        HIP_TRY(hipMalloc((void **)&st.d_stamps, sizeof(unsigned long long) * per_product * (size_t)ring));
+        HIP_TRY(hipMalloc((void **)&st.d_first_last, sizeof(unsigned long long) * 2 * (size_t)super + sizeof(unsigned) * (size_t)launches_per_super));
+        HIP_TRY(hipMalloc((void **)&st.d_ctl, sizeof(unsigned) * smvp::kRepeatCtlWords));
+        d_tops = reinterpret_cast<unsigned *>(st.d_first_last + 2 * (size_t)super);
+        std::vector<unsigned long long> fl((size_t)super * 2);
+        std::vector<unsigned> tops((size_t)launches_per_super);
+        repeated = true;
+        for (int s0 = 0; s0 < iters && repeated; s0 += super) {
+            const int ns = std::min(super, iters - s0);
+            int launches = 0;
+            for (int i0 = 0; i0 < ns; i0 += ring, ++launches) {
+                const int n = std::min(ring, ns - i0);
+                if (int rc = repeat(xc, yc, st.d_stamps, n, repeat_grid, st.d_ctl))
+                    return rc;
+                HIP_TRY(smvp::launch_stamp_reduce(st.d_stamps, slots, n, st.d_first_last + 2 * (size_t)i0, s.stream));
+                HIP_TRY(hipMemcpyAsync(d_tops + launches, st.d_ctl + smvp::kRepeatCtlWords - 32, sizeof(unsigned), hipMemcpyDeviceToDevice, s.stream));
+            }
+            HIP_TRY(hipMemcpyAsync(fl.data(), st.d_first_last, sizeof(unsigned long long) * 2 * (size_t)ns, hipMemcpyDeviceToHost, s.stream));
+            HIP_TRY(hipMemcpyAsync(tops.data(), d_tops, sizeof(unsigned) * (size_t)launches, hipMemcpyDeviceToHost, s.stream));
+            HIP_TRY(hipStreamSynchronize(s.stream));
+            for (int l = 0; l < launches; ++l)
+                if (tops[(size_t)l] & 0x80000000u)
+                    repeated = false;  // gave up at a barrier: nothing of this run is trusted
+            if (!repeated)
+                break;
+            g_last_run.repeat_launches += launches;
+            for (int k = 0; k < ns; ++k)
+                s.ms[(size_t)(s0 + k)] = (double)(fl[2 * (size_t)k + 1] - fl[2 * (size_t)k]) / (double)khz;
+        }
+        if (!repeated)
+            g_last_run.repeat_launches = 0;
+        s.d_result = yc;
+    }
+    if (stamped && !repeated) {
         StampTimer st;
         const size_t per_product = (size_t)stamp_slots * 2;
         const int ring = std::min(iters, kStampRing);
@@ -1691,7 +1778,7 @@ int run_timed_products(RunScratch &s, int rows, int iters, const smvp_run_opts_t
                 s.ms[(size_t)(i0 + k)] = (double)(fl[2 * (size_t)k + 1] - fl[2 * (size_t)k]) / (double)khz;
         }
         s.d_result = yc;
-    } else {
+    } else if (!stamped) {
         for (int i = 0; i < iters; ++i) {
             if (int rc = pre(yc))
                 return rc;
@@ -1819,9 +1906,13 @@ extern "C" int smvp_csr_compute(const smvp_coo_t *coo, int rows, int cols, int n
     HIP_TRY(hipMemsetAsync(s.d_y, 0xff, sizeof(double) * (size_t)std::max(rows, 1), s.stream));
     smvp_csr_t *A = s.csr;
     const int slots = csr_can_stamp(A) ? smvp::owner_stamp_slots(A->ntiles, A->flavor) : 0;
+    const int rgrid = slots > 0 ? csr_repeat_grid(A) : 0;  // the tile kernel's repeating form: n products per launch
     if (int rc = run_timed_products(
             s, rows, iters, o, slots, [](double *) { return (int)SMVP_OK; },
-            [A, &s](const double *x, double *yy, unsigned long long *stamps) { return csr_spmv_impl(A, x, yy, s.stream, stamps); }))
+            [A, &s](const double *x, double *yy, unsigned long long *stamps) { return csr_spmv_impl(A, x, yy, s.stream, stamps); }, rgrid,
+            [A, &s](const double *x, double *yy, unsigned long long *stamps, int reps, int grid, unsigned *ctl) {
+                return csr_spmv_repeat(A, x, yy, s.stream, stamps, reps, grid, ctl);
+            }))
         return rc;
     return finish_run(s, rows, iters, y, time_each_ms, stats);
 }
@@ -1901,6 +1992,10 @@ extern "C" int smvp_tjds_compute(const smvp_coo_t *coo, int rows, int cols, int 
                         return rc;
                 first = false;
                 return tjds_spmv_impl(T, yy, s.stream, stamps);
+            },
+            slots > 0 ? csr_repeat_grid(T->rg) : 0,  // (tjds_can_stamp: the row-gather product, which overwrites y and needs no `pre`)
+            [T, &s](const double *, double *yy, unsigned long long *stamps, int reps, int grid, unsigned *ctl) {
+                return csr_spmv_repeat(T->rg, T->d_x_perm, yy, s.stream, stamps, reps, grid, ctl);
             }))
         return rc;
     return finish_run(s, rows, iters, y, time_each_ms, stats);

@@ -57,6 +57,13 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
 void debug_owner_phases();
 void debug_binned_phases();
 int owner_stamp_slots(int ntiles, int flavor);  // {first, last} tick pairs one stamped launch writes
+// the repeating form: `reps` products in one launch, every product's window stamped (csr_stream_owner_repeat).  grid =
+// owner_repeat_grid(...) workgroups (0: no such form for this plan / device), stamps = reps * grid * 4 {first, last} pairs in
+// l.stamps, ctl_words = kRepeatCtlWords unsigned of device memory; *top bit 31 set afterwards = the launch gave up (abort)
+constexpr int kRepeatCtlWords = 32 * 65;  // 32 shard counters, 32 go words, the top counter (bit 31: abort; the last line), each on a 128-byte line of its own
+int owner_repeat_grid(int vpt, int flavor, int ntiles);
+hipError_t launch_csr_stream_owner_repeat(int vpt, int flavor, const OwnerLaunch &l, int reps, int grid, unsigned *ctl_words,
+                                          hipStream_t stream);
 hipError_t launch_stamp_reduce(const unsigned long long *stamps, int slots_per_product, int products,
                                unsigned long long *first_last, hipStream_t stream);
 hipError_t launch_tjds_products(const int *start_pos, const double *val, const double *x_perm, double *prod,

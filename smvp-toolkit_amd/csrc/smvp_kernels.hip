@@ -299,11 +299,13 @@ __device__ unsigned long long g_owner_phase[8];
 #define SMVP_PHASE(n) do { } while (0)
 #endif
 
+// The body of the owner kernel for workgroup number `block` of the launch's grid (the plain kernel passes blockIdx.x; the
+// repeating kernel below walks the same grid several times).  Every thread of the workgroup leaves through the same exit.
 template <int VPT, int FLAVOR, bool STAMPED>
-__global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
+__device__ __forceinline__ void owner_body(
     const int *__restrict__ row_ptr, const int *__restrict__ col_ind, const double *__restrict__ val,
     const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ tile_row,
-    const int *__restrict__ tile_next, int rows, int nnz_arg, int ntiles, int tile_group_arg, const OwnerExtra ex)
+    const int *__restrict__ tile_next, int rows, int nnz_arg, int ntiles, int tile_group_arg, const OwnerExtra &ex, const int block)
 {
     const OwnerArgs a = {col_ind, val, x, ex.pos, ex.start_pos, ex.ovf_pos, ex.ovf_k};
     constexpr int TILE = kStreamBlock * VPT;
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     // free of launch and event overhead (the engine reduces the slots, see stamp_reduce)
     unsigned long long *stamp = nullptr;
     if constexpr (STAMPED) {
-        stamp = ex.stamps + 2 * ((size_t)blockIdx.x * (kStreamBlock / 64) + (t >> 6));
+        stamp = ex.stamps + 2 * ((size_t)block * (kStreamBlock / 64) + (t >> 6));
         if ((t & 63) == 0)
             stamp[0] = wall_clock64();
     }
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
         return;                                                   \
     } while (0)
 
-    const int b = tile_of_block(blockIdx.x, tile_group_arg);
+    const int b = tile_of_block(block, tile_group_arg);
     if (b >= ntiles)
         SMVP_OWNER_EXIT();
     const int nnz = nnz_arg;
@@ -377,8 +379,13 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
         if (full_tile) {
 #pragma unroll
             for (int k = 0; k < VPT; ++k) {
-                pj[k] = __builtin_nontemporal_load(a.pos + s + k * kStreamBlock + t);
-                c[k] = __builtin_nontemporal_load(ex.meta16 + s + k * kStreamBlock + t);  // slot | run hint << kSlotBits
+                if constexpr (VPT == 1) {  // 256-entry tiles: a matrix that lives in the caches and is multiplied again and again
+                    pj[k] = a.pos[s + k * kStreamBlock + t];
+                    c[k] = ex.meta16[s + k * kStreamBlock + t];
+                } else {
+                    pj[k] = __builtin_nontemporal_load(a.pos + s + k * kStreamBlock + t);
+                    c[k] = __builtin_nontemporal_load(ex.meta16 + s + k * kStreamBlock + t);  // slot | run hint << kSlotBits
+                }
                 grp[k] = ex.group_run[(size_t)b * (TILE / 32) + ((k * kStreamBlock + t) >> 5)];
             }
         }
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
         if (full_tile) {
 #pragma unroll
             for (int k = 0; k < VPT; ++k) {
-                if (ex.stream_nt) {
+                if (ex.stream_nt && VPT > 1) {
                     pj[k] = __builtin_nontemporal_load(a.pos + s + k * kStreamBlock + t);
                     c[k] = __builtin_nontemporal_load(a.col_ind + s + k * kStreamBlock + t);
                 } else {
@@ -609,7 +616,12 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
                 if (i + 3 < rz)
                     acc += v3;
             }
-            __builtin_nontemporal_store(acc, &y[r]);
+            // (256-entry tiles are what matrices that live in the caches get: there a plain store is acknowledged by the L2,
+            // sooner than a non-temporal one by memory -- and the product's window ends with that acknowledgement)
+            if constexpr (VPT == 1)
+                y[r] = acc;
+            else
+                __builtin_nontemporal_store(acc, &y[r]);
         } else {
             const int q = atomicAdd(&long_count, 1);
             long_rows[q] = r;
@@ -681,6 +693,132 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
     }
     SMVP_OWNER_EXIT();
 #undef SMVP_OWNER_EXIT
+}
+
+template <int VPT, int FLAVOR, bool STAMPED>
+__global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
+    const int *__restrict__ row_ptr, const int *__restrict__ col_ind, const double *__restrict__ val,
+    const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ tile_row,
+    const int *__restrict__ tile_next, int rows, int nnz_arg, int ntiles, int tile_group_arg, const OwnerExtra ex)
+{
+    owner_body<VPT, FLAVOR, STAMPED>(row_ptr, col_ind, val, x, y, tile_row, tile_next, rows, nnz_arg, ntiles, tile_group_arg, ex,
+                                     (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+// K2-repeat: `reps` products in ONE launch, each with a window of its own -- for the reference's own use case, -n 1000 on a
+// matrix that lives in the caches (main-cli.c:402-420: the same product, the same x, n times).  A launch boundary costs such
+// a product as much as the product (memplus.mtx: 3.0 us in the kernel, 4.9 us from dispatch to dispatch in a hipGraph, 6.4 us of
+// loop wall per product: profiles/r04_cli_n1000.txt).  Here the workgroups stay: every one walks its share of the launch's
+// grid once per product, and between two products all of them meet at a barrier that orders TIME only -- the products
+// are independent (x is never changed, y is overwritten with the same values), so nothing has to become visible to anybody
+// and the barrier needs no release / acquire fences (which are what a grid barrier mostly costs: MI355X_MICROARCH price
+// list, barrier-xcd): arrivals are counted on about sqrt(workgroups) sharded counters (device-scope atomics run at the memory
+// side, ~12 ns each on one address: different addresses take them in parallel), the last arrival of a shard counts on a top counter,
+// everybody polls that one with sc1 loads.  Every wave stamps the wall clock when it passes the barrier into product i and
+// when its last store of product i has been acknowledged: the same {first, last} slots the stamped single launches write,
+// reduced by stamp_reduce -- windows that cannot overlap, one per product, inside one launch.
+//
+// The grid must be resident as a whole (the launcher sizes it from the occupancy query, with a margin); every poll is
+// bounded all the same: a workgroup that waits longer than kRepeatPatience wall-clock ticks sets the top counter's abort bit,
+// everybody leaves, and the host falls back to single launches.
+// ---------------------------------------------------------------------------
+constexpr int kRepeatMaxShards = 32;
+constexpr unsigned kRepeatAbort = 0x80000000u;
+constexpr unsigned long long kRepeatPatience = 300ull * 1000 * 1000;  // 3 s of the 100 MHz wall clock
+
+struct RepeatCtl {
+    unsigned *shard;           // `shards` counters, 32 words (128 B) apart
+    unsigned *top;             // one counter; bit 31 = abort
+    unsigned *go;              // `shards` generation words, 128 B apart: what the workgroups of a shard poll (sharded grids)
+    unsigned long long *stamps;  // reps * slots_per_product * 2
+    int reps, grid_virtual, slots_per_product;
+    int shards;                // 1: every workgroup counts on `top` itself (small grids); else about sqrt(workgroups), a power of two
+};
+
+template <int VPT, int FLAVOR>
+__global__ __launch_bounds__(kStreamBlock) void csr_stream_owner_repeat(
+    const int *__restrict__ row_ptr, const int *__restrict__ col_ind, const double *__restrict__ val,
+    const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ tile_row,
+    const int *__restrict__ tile_next, int rows, int nnz_arg, int ntiles, int tile_group_arg, const OwnerExtra ex, const RepeatCtl ctl)
+{
+    __shared__ unsigned go;
+    const int t = threadIdx.x;
+    const unsigned nwg = gridDim.x, me = blockIdx.x;
+    const unsigned S = (unsigned)ctl.shards;
+    const unsigned sh = me % S;
+    const unsigned members = (nwg - sh + S - 1) / S;   // workgroups of this shard
+    const unsigned arrivals = S > 1 ? (nwg < S ? nwg : S) : nwg;  // what `top` counts per product: shards with members, or workgroups
+    unsigned long long *stamp = ctl.stamps + 2 * ((size_t)me * (kStreamBlock / 64) + (t >> 6));
+    for (int rep = 0; rep < ctl.reps; ++rep) {
+        // ---- every workgroup has finished product rep - 1 (its stores acknowledged) before anybody starts product rep
+        __syncthreads();
+        if (t == 0) {
+            const unsigned gen = (unsigned)rep + 1u;
+            const unsigned long long t0 = wall_clock64();
+            unsigned seen = 0;
+            if (S > 1) {
+                // arrivals: shard counter, its last arrival on the top counter, ITS last arrival writes the generation into
+                // every shard's go word -- which is what a shard's workgroups poll: polls and arrivals never meet on one
+                // address (all workgroups polling the top counter held up the arrivals on it: 32 shards 7.0 us per product
+                // against 4.96 with 8, memplus.mtx; a one-level form in which every workgroup's first wavefront polled all
+                // shard counters ran at 7-15 us: the polls also slow the workgroups that are still multiplying;
+                // profiles/r05_cli_n1000.txt)
+                const unsigned before = atomicAdd(ctl.shard + 32 * sh, 1u);
+                if (before + 1u == members * gen) {
+                    const unsigned tb = atomicAdd(ctl.top, 1u);
+                    if ((tb & ~kRepeatAbort) + 1u == arrivals * gen)
+                        for (unsigned q = 0; q < S; ++q)
+                            __hip_atomic_store(ctl.go + 32 * q, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                for (;;) {
+                    const unsigned g = __hip_atomic_load(ctl.go + 32 * sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (g >= gen && g != kRepeatAbort)
+                        break;
+                    if (g == kRepeatAbort) {
+                        seen = kRepeatAbort;
+                        break;
+                    }
+                    if (wall_clock64() - t0 > kRepeatPatience) {
+                        atomicOr(ctl.top, kRepeatAbort);
+                        for (unsigned q = 0; q < S; ++q)
+                            __hip_atomic_store(ctl.go + 32 * q, kRepeatAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        seen = kRepeatAbort;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            } else {
+                atomicAdd(ctl.top, 1u);  // (result unused: no round trip in front of the poll)
+                for (;;) {
+                    seen = __hip_atomic_load(ctl.top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((seen & kRepeatAbort) || (seen & ~kRepeatAbort) >= arrivals * gen)
+                        break;
+                    if (wall_clock64() - t0 > kRepeatPatience) {
+                        atomicOr(ctl.top, kRepeatAbort);
+                        seen = kRepeatAbort;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            go = seen & kRepeatAbort ? 0u : 1u;
+        }
+        __syncthreads();
+        if (!go)
+            return;  // (uniform: the whole workgroup read the same word)
+        if ((t & 63) == 0)
+            stamp[0] = wall_clock64();
+        for (int vb = (int)me; vb < ctl.grid_virtual; vb += (int)nwg) {
+            if (vb != (int)me)
+                __syncthreads();  // the previous tile's LDS is free
+            owner_body<VPT, FLAVOR, false>(row_ptr, col_ind, val, x, y, tile_row, tile_next, rows, nnz_arg, ntiles, tile_group_arg, ex, vb);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((t & 63) == 0)
+            stamp[1] = wall_clock64();
+        stamp += 2 * (size_t)ctl.slots_per_product;
+    }
 }
 
 // One workgroup per product of a stamped run: min of the waves' first ticks, max of their last.
@@ -1002,6 +1140,87 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
     SMVP_OWNER(8, kFlavorTjdsH)
 #undef SMVP_OWNER
 #undef SMVP_OWNER_ST
+    return hipErrorInvalidValue;
+}
+
+// ---- the repeating form (csr_stream_owner_repeat): `reps` products in one launch
+// Workgroups of the repeating launch for a plan of `ntiles` tiles: the plain launch's grid, capped so that the whole grid is
+// resident at once with room to spare (the occupancy query can read one workgroup per CU high, MI355X_MICROARCH "Residency");
+// 0: this (vpt, flavor) has no repeating form, or the device could not be asked.
+template <int V, int F>
+static int repeat_capacity()
+{
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, csr_stream_owner_repeat<V, F>, kStreamBlock, 0) != hipSuccess ||
+        hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return per_cu > 1 ? (per_cu - 1) * cus / 2 : 0;  // half of (one workgroup per CU fewer than the query's answer)
+}
+
+#define SMVP_REPEAT_FORMS(X) \
+    X(1, kFlavorCsr) X(4, kFlavorCsr) X(8, kFlavorCsr) X(4, kFlavorCsr16) X(8, kFlavorCsr16) \
+    X(1, kFlavorTjdsS) X(4, kFlavorTjdsS) X(8, kFlavorTjdsS) X(1, kFlavorTjdsH) X(4, kFlavorTjdsH) X(8, kFlavorTjdsH)
+
+int owner_repeat_grid(int vpt, int flavor, int ntiles)
+{
+    if (ntiles <= 0)
+        return 0;
+    int cap = 0;
+#define X(V, F)                     \
+    if (vpt == V && flavor == F)    \
+        cap = repeat_capacity<V, F>();
+    SMVP_REPEAT_FORMS(X)
+#undef X
+    if (cap <= 0)
+        return 0;
+    const int full = (int)owner_grid(ntiles, tile_group(ntiles, flavor_group(flavor)));
+    return full < cap ? full : cap;
+}
+
+// `reps` products, each stamped: stamps[reps][grid * 4][2]; ctl_words: kRepeatCtlWords unsigned, cleared here.
+hipError_t launch_csr_stream_owner_repeat(int vpt, int flavor, const OwnerLaunch &l, int reps, int grid, unsigned *ctl_words,
+                                          hipStream_t stream)
+{
+    if (l.rows <= 0 || reps <= 0)
+        return hipSuccess;
+    if (grid <= 0 || !l.stamps || !ctl_words)
+        return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(ctl_words, 0, sizeof(unsigned) * kRepeatCtlWords, stream);
+    if (e != hipSuccess)
+        return e;
+    const int group = tile_group(l.ntiles, flavor_group(flavor));
+    static const int nt = [] {
+        const char *env = getenv("SMVP_TJDS_NT");  // development switch (see launch_csr_stream_owner)
+        return env ? atoi(env) : 1;
+    }();
+    OwnerExtra ex;
+    ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_pos = l.ovf_pos, ex.ovf_k = l.ovf_k;
+    ex.cache_ptr = l.cache_ptr, ex.val_cache = l.val_cache;
+    ex.col16 = l.col16, ex.col_base = l.col_base;
+    ex.meta16 = l.meta16, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_sp = l.run_sp;
+    ex.stamps = nullptr, ex.stream_nt = nt;
+    RepeatCtl ctl;
+    ctl.shard = ctl_words, ctl.go = ctl_words + 32 * kRepeatMaxShards, ctl.top = ctl_words + kRepeatCtlWords - 32;
+    // arrivals cost about 12 ns each on one address: n / S on a shard, then S on the top counter
+    // measured (profiles/r05_cli_n1000.txt): one level up to two dozen workgroups, 8 shards up to ~600, 16 beyond
+    ctl.shards = grid <= 24 ? 1 : grid <= 640 ? 8 : 16;
+    if (const char *env = getenv("SMVP_REPEAT_SHARDS")) {  // development switch (start of a run): 1, 2, 4 ... 32
+        const int v = atoi(env);
+        if (v >= 1 && v <= kRepeatMaxShards && (v & (v - 1)) == 0)
+            ctl.shards = v;
+    }
+    ctl.stamps = l.stamps;
+    ctl.reps = reps, ctl.grid_virtual = (int)owner_grid(l.ntiles, group), ctl.slots_per_product = grid * (kStreamBlock / 64);
+#define X(V, F)                                                                                                                    \
+    if (vpt == V && flavor == F) {                                                                                                 \
+        hipLaunchKernelGGL((csr_stream_owner_repeat<V, F>), dim3((unsigned)grid), dim3(kStreamBlock), 0, stream, l.row_ptr, l.col_ind, \
+                           l.val, l.x, l.y, l.tile_row, l.tile_next, l.rows, l.nnz, l.ntiles, group, ex, ctl);                     \
+        return hipGetLastError();                                                                                                  \
+    }
+    SMVP_REPEAT_FORMS(X)
+#undef X
     return hipErrorInvalidValue;
 }
 

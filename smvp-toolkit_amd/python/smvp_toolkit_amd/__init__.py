@@ -45,7 +45,8 @@ class PlanInfo(C.Structure):
 
 
 class RunInfo(C.Structure):
-    _fields_ = [("timing", C.c_int), ("graph_replays", C.c_int), ("wall_ms", C.c_double), ("device_clock_khz", C.c_double)]
+    _fields_ = [("timing", C.c_int), ("graph_replays", C.c_int), ("wall_ms", C.c_double), ("device_clock_khz", C.c_double),
+                ("repeat_launches", C.c_int), ("reserved", C.c_int)]
 
 
 class ShardOpts(C.Structure):
