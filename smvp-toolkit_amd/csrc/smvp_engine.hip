@@ -123,7 +123,8 @@ struct smvp_csr {
     const int *d_start_pos = nullptr;
     int num_diag = 0;
     // TjdsS: per-tile TJDS-ordered streams and the tiles' overflow entries, owned, rebuilt with the tile plan
-    int *d_pos_sorted = nullptr, *d_meta = nullptr, *d_ovf_ptr = nullptr, *d_ovf_pos = nullptr, *d_ovf_k = nullptr;
+    int *d_pos_sorted = nullptr, *d_meta = nullptr, *d_ovf_ptr = nullptr, *d_ovf_k = nullptr;
+    double *d_ovf_val = nullptr;  // TjdsS / H: the overflow entries' values (read coalesced by the tile that finishes the row)
     // TjdsS: values of the entries whose val lines scatter over cache_min_tiles tiles or more, kept tile by tile (0: none).
     // A line split over two or three tiles is the edge between neighbouring tiles (they run together on one XCD: an L2
     // hit); from four on its entries belong to unrelated rows.  Measured on memplus x944 (profiles/r03_tjds_forms_measured.txt):
@@ -383,12 +384,13 @@ void free_stream_plan(smvp_csr *h)
         (void)hipFree(h->d_col_base);
     h->d_col16 = nullptr;
     h->d_col_base = nullptr;
-    for (void *p : {(void *)h->d_pos_sorted, (void *)h->d_meta, (void *)h->d_ovf_ptr, (void *)h->d_ovf_pos, (void *)h->d_ovf_k,
+    for (void *p : {(void *)h->d_pos_sorted, (void *)h->d_meta, (void *)h->d_ovf_ptr, (void *)h->d_ovf_val, (void *)h->d_ovf_k,
                     (void *)h->d_cache_ptr, (void *)h->d_val_cache, (void *)h->d_meta16, (void *)h->d_group_run,
                     (void *)h->d_run_ptr, (void *)h->d_run_sp})
         if (p)
             (void)hipFree(p);
-    h->d_pos_sorted = h->d_meta = h->d_ovf_ptr = h->d_ovf_pos = h->d_ovf_k = h->d_cache_ptr = nullptr;
+    h->d_pos_sorted = h->d_meta = h->d_ovf_ptr = h->d_ovf_k = h->d_cache_ptr = nullptr;
+    h->d_ovf_val = nullptr;
     h->d_run_ptr = h->d_run_sp = nullptr;
     h->d_meta16 = h->d_group_run = nullptr;
     h->d_val_cache = nullptr;
@@ -482,7 +484,7 @@ int build_stream_plan(smvp_csr *h)
             return rc;
         const size_t n = (size_t)std::max(h->nnz, 4), m = (size_t)std::max(total, 4);
         if (hipMalloc((void **)&h->d_pos_sorted, n * sizeof(int)) != hipSuccess ||
-            hipMalloc((void **)&h->d_ovf_pos, m * sizeof(int)) != hipSuccess ||
+            hipMalloc((void **)&h->d_ovf_val, m * sizeof(double)) != hipSuccess ||
             hipMalloc((void **)&h->d_ovf_k, m * sizeof(int)) != hipSuccess ||
             hipMalloc((void **)&h->d_cache_ptr, ((size_t)ntiles + 2) * sizeof(int)) != hipSuccess)
             return smvp::fail(SMVP_ERR_ALLOC, "cannot allocate the tile-ordered TJDS streams");
@@ -504,7 +506,7 @@ int build_stream_plan(smvp_csr *h)
                 return rc;
         }
         if (int rc = smvp::build_tile_overflow(h->d_pos, h->d_ovf_ptr, total, ntiles, tile, h->nnz, h->d_start_pos,
-                                               h->num_diag, h->d_ovf_pos, h->d_ovf_k, nullptr))
+                                               h->num_diag, h->d_val, h->d_ovf_val, h->d_ovf_k, nullptr))
             return rc;
     }
     return SMVP_OK;
@@ -819,7 +821,7 @@ static void fill_owner_launch(const smvp_csr_t *h, const double *d_x, double *d_
     l.pos = h->d_pos, l.start_pos = h->d_start_pos;
     if (h->flavor == smvp::kFlavorTjdsS || h->flavor == smvp::kFlavorTjdsH) {
         l.pos = h->d_pos_sorted, l.col_ind = h->d_meta;
-        l.ovf_ptr = h->d_ovf_ptr, l.ovf_pos = h->d_ovf_pos, l.ovf_k = h->d_ovf_k;
+        l.ovf_ptr = h->d_ovf_ptr, l.ovf_val = h->d_ovf_val, l.ovf_k = h->d_ovf_k;
         l.cache_ptr = h->d_cache_ptr, l.val_cache = h->d_val_cache;
         l.meta16 = h->d_meta16, l.group_run = h->d_group_run, l.run_ptr = h->d_run_ptr, l.run_sp = h->d_run_sp;
     }
@@ -1002,7 +1004,7 @@ static double csr_plan_bytes(const smvp_csr_t *h)
     if (h->d_col16)
         b += 2.0 * n + 4.0 * (n / 1024 + 1);
     if (h->flavor == smvp::kFlavorTjdsS || h->flavor == smvp::kFlavorTjdsH) {
-        b += 4.0 * n + 4.0 * (t + 1) + 8.0 * h->ovf_total + 4.0 * (t + 2) + 8.0 * h->cached_total;
+        b += 4.0 * n + 4.0 * (t + 1) + 12.0 * h->ovf_total + 4.0 * (t + 2) + 8.0 * h->cached_total;
         b += h->flavor == smvp::kFlavorTjdsH ? 2.0 * n + 4.0 * (t + 2) + 4.0 * h->runs_total + 2.0 * (n / 32 + 1) : 4.0 * n;
     }
     return b;

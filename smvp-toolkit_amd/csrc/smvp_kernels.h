@@ -42,7 +42,8 @@ struct OwnerLaunch {
     const int *pos = nullptr;
     const int *start_pos = nullptr;
     unsigned long long *stamps = nullptr;  // owner_stamp_slots(ntiles) pairs, or nullptr
-    const int *ovf_ptr = nullptr, *ovf_pos = nullptr, *ovf_k = nullptr;  // kFlavorTjdsS
+    const int *ovf_ptr = nullptr, *ovf_k = nullptr;  // kFlavorTjdsS / H: the tiles' overflow entries (permuted column ...
+    const double *ovf_val = nullptr;                 // ... and value), row order
     const int *cache_ptr = nullptr;                                      // kFlavorTjdsS
     const double *val_cache = nullptr;
     const unsigned short *col16 = nullptr;                               // kFlavorCsr16

@@ -227,8 +227,8 @@ typedef int int4v __attribute__((ext_vector_type(4)));               // clang ve
 struct OwnerExtra {
     const int *pos;                 // Tjds*: TJDS position of each stream entry
     const int *start_pos;           // TjdsS
-    const int *ovf_ptr;             // TjdsS: ntiles + 1 bounds of the tiles' overflow entries in ovf_pos / ovf_k
-    const int *ovf_pos;             // TjdsS: TJDS position ...
+    const int *ovf_ptr;             // TjdsS: ntiles + 1 bounds of the tiles' overflow entries in ovf_val / ovf_k
+    const double *ovf_val;          // TjdsS: value ...
     const int *ovf_k;               // TjdsS: ... and permuted column of the entries [e, tile_next) of each tile, row order
     const int *cache_ptr;           // TjdsS: ntiles + 1 bounds of the tiles' runs in val_cache (a tile's last entries)
     const double *val_cache;        // TjdsS: values of the entries whose val lines scatter over many tiles, tile by tile
@@ -249,7 +249,7 @@ struct OwnerArgs {
     const double *__restrict__ x;
     const int *__restrict__ pos;
     const int *__restrict__ start_pos;
-    const int *__restrict__ ovf_pos;
+    const double *__restrict__ ovf_val;
     const int *__restrict__ ovf_k;
 };
 
@@ -274,7 +274,7 @@ template <int FLAVOR>
 __device__ __forceinline__ double owner_overflow_product(const OwnerArgs &a, int ovf_base, int e, int i)
 {
     if constexpr (FLAVOR == kFlavorTjdsS || FLAVOR == kFlavorTjdsH)
-        return a.val[a.ovf_pos[ovf_base + i]] * a.x[a.ovf_k[ovf_base + i]];
+        return a.ovf_val[ovf_base + i] * a.x[a.ovf_k[ovf_base + i]];
     else
         return owner_product_slow<FLAVOR>(a, (long long)e + i);
 }
@@ -299,6 +299,14 @@ __device__ unsigned long long g_owner_phase[8];
 #define SMVP_PHASE(n) do { } while (0)
 #endif
 
+// Diagnostic builds only (make ... HIPFLAGS+=-DSMVP_TJDS_NEUTRALISE=mask; tools/tjds_traffic_by_stream.sh): the tile-ordered TJDS
+// product with one of its streams taken out -- WRONG results, the PMC counters then show what that stream moves.
+// 1: the x_perm gathers (operand 1.0)   2: the in-place val gathers (val[position])   4: the value cache's reads
+// 8: the overflow entries (their index, value and operand loads).  The normal build contains none of this.
+#ifndef SMVP_TJDS_NEUTRALISE
+#define SMVP_TJDS_NEUTRALISE 0
+#endif
+
 // The body of the owner kernel for workgroup number `block` of the launch's grid (the plain kernel passes blockIdx.x; the
 // repeating kernel below walks the same grid several times).  Every thread of the workgroup leaves through the same exit.
 template <int VPT, int FLAVOR, bool STAMPED>
@@ -307,7 +315,7 @@ __device__ __forceinline__ void owner_body(
     const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ tile_row,
     const int *__restrict__ tile_next, int rows, int nnz_arg, int ntiles, int tile_group_arg, const OwnerExtra &ex, const int block)
 {
-    const OwnerArgs a = {col_ind, val, x, ex.pos, ex.start_pos, ex.ovf_pos, ex.ovf_k};
+    const OwnerArgs a = {col_ind, val, x, ex.pos, ex.start_pos, ex.ovf_val, ex.ovf_k};
     constexpr int TILE = kStreamBlock * VPT;
     constexpr int QCAP = (TILE + kStreamOver) / kLongRow + 1;
     constexpr bool CSR = FLAVOR == kFlavorCsr || FLAVOR == kFlavorCsr16;
@@ -478,9 +486,10 @@ __device__ __forceinline__ void owner_body(
             rp_a2 = row_ptr[rlo + t + kStreamBlock];
             rp_b2 = row_ptr[rlo + t + kStreamBlock + 1];
         }
-        int co = 0, pjo = 0;
-        if (over0) {
-            pjo = a.ovf_pos[ovf_base + t];
+        int co = 0;
+        double vo = 0.0;
+        if (over0 && !(SMVP_TJDS_NEUTRALISE & 8)) {
+            vo = a.ovf_val[ovf_base + t];
             co = a.ovf_k[ovf_base + t];
         }
         if (full_tile) {
@@ -505,13 +514,17 @@ __device__ __forceinline__ void owner_body(
             for (int k = 0; k < VPT; ++k) {
                 const int idx = k * kStreamBlock + t;
                 const double *src = idx < in_place ? a.val + pj[k] : ex.val_cache + (cache0 + (idx - in_place));
-                v[k] = *src;
+                if ((SMVP_TJDS_NEUTRALISE & 2) && idx < in_place)
+                    v[k] = 1.0;
+                else if ((SMVP_TJDS_NEUTRALISE & 4) && idx >= in_place)
+                    v[k] = 1.0;
+                else
+                    v[k] = *src;
             }
-            const double vo = over0 ? a.val[pjo] : 0.0;
 #pragma unroll
             for (int k = 0; k < VPT; ++k)
-                xk[k] = a.x[c[k]];
-            const double xo = over0 ? a.x[co] : 0.0;
+                xk[k] = (SMVP_TJDS_NEUTRALISE & 1) ? 1.0 : a.x[c[k]];
+            const double xo = over0 && !(SMVP_TJDS_NEUTRALISE & 8) ? a.x[co] : 0.0;
 #pragma unroll
             for (int k = 0; k < VPT; ++k)
                 prod[slot[k]] = v[k] * xk[k];
@@ -533,7 +546,7 @@ __device__ __forceinline__ void owner_body(
                 }
             }
             if (over0)
-                po = a.val[pjo] * a.x[co];
+                po = vo * a.x[co];
         }
     } else if (whole) {
         if (rlo + t < rhi) {  // this lane's first row in phase 2
@@ -1105,7 +1118,7 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
         return e ? atoi(e) : 1;
     }();
     OwnerExtra ex;
-    ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_pos = l.ovf_pos, ex.ovf_k = l.ovf_k;
+    ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_val = l.ovf_val, ex.ovf_k = l.ovf_k;
     ex.cache_ptr = l.cache_ptr, ex.val_cache = l.val_cache;
     ex.col16 = l.col16, ex.col_base = l.col_base;
     ex.meta16 = l.meta16, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_sp = l.run_sp;
@@ -1196,7 +1209,7 @@ hipError_t launch_csr_stream_owner_repeat(int vpt, int flavor, const OwnerLaunch
         return env ? atoi(env) : 1;
     }();
     OwnerExtra ex;
-    ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_pos = l.ovf_pos, ex.ovf_k = l.ovf_k;
+    ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_val = l.ovf_val, ex.ovf_k = l.ovf_k;
     ex.cache_ptr = l.cache_ptr, ex.val_cache = l.val_cache;
     ex.col16 = l.col16, ex.col_base = l.col_base;
     ex.meta16 = l.meta16, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_sp = l.run_sp;

@@ -547,7 +547,7 @@ def test_plan_info_bounds(torch):
     T = sm.TjdsMatrix(sm.tjds_from_coo(coo, m, n))
     t = T.plan_info()
     assert t["matrix_bytes"] == 12.0 * len(val) + 4.0 * (T.t.num_diag + 1) + 4.0 * n if hasattr(T, "t") else t["matrix_bytes"] > 12.0 * len(val)
-    assert 0.5 * t["matrix_bytes"] < t["plan_bytes"] < 1.6 * t["matrix_bytes"] and t["build_ms"] > 0
+    assert 0.5 * t["matrix_bytes"] < t["plan_bytes"] < 1.7 * t["matrix_bytes"] and t["build_ms"] > 0
     T.set_mode(sm.TJDS_MODE_TWO_PHASE)
     assert T.plan_info()["plan_bytes"] > t["plan_bytes"] + 12.0 * len(val)       # + the products and the row-inverted index
     T.close()
