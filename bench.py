@@ -30,10 +30,18 @@ With N > 1 the headline matrix is cut into N row blocks, one process per GPU, an
 step is the local product plus the RCCL all-gather of the y blocks over xGMI
 (strong scaling).
 
+Started as plain `python bench.py --gpus N` (N > 1, no RANK / WORLD_SIZE in the environment: the driver's command shape)
+the script is its own launcher: before torch or HIP are touched it starts the N ranks as child processes and relays
+rank 0's line (spawn_ranks).
+
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM
 (algorithmic bytes of SURVEY 8(d) / measured time per launch); `cpu_baseline` is the
 reference's serial loop (the C oracle's restatement of main-cli.c:410-416) timed on
-this box's host, one thread.
+this box's host, one thread.  The driver's record keeps the SCALAR keys of `roofline` (and of
+`cpu_baseline` / `config`) and drops nested objects: every figure a record needs -- the other kernels'
+fractions, traffic over algorithmic bytes, config 4's t1 / tN / speed-up keys, the C layer's legs and exchange
+times, the sample matrices' microseconds, what the communicator reports -- is therefore also a flat scalar in
+`roofline` (flat_keys); `roofline.others` and `extra` carry the detail for a human reader.
 """
 import argparse
 import json
@@ -1423,7 +1431,8 @@ def main():
 
     # ------------------------------------------------------------ roofline.others: every other kernel the line reports,
     # priced like the headline (algorithmic bytes of SURVEY 8(d) per product / measured time; traffic from this run's
-    # own --pmc child passes where they ran).  `extra` repeats these with more detail.
+    # own --pmc child passes where they ran).  `extra` repeats these with more detail.  (The driver's parse drops nested
+    # objects: flat_keys below repeats the figures that matter as scalars of `roofline`.)
     def other(kernel, ms, alg, nnz, key=None, **more):
         o = {"kernel": kernel, "ms_per_product": round(ms, 5), "alg_bytes_per_product": alg,
              "achieved": round(alg / ms * 1e-6, 1), "unit": "GB/s", "frac": round(alg / ms * 1e-6 / HBM_PEAK_GBS, 4),
