@@ -394,9 +394,11 @@ void smvp_run_opts_default(smvp_run_opts_t *o);
  * products are independent) barrier between two products; where that form is not available (or gives up: the grid must be
  * resident as a whole) the products are replayed one launch each from a hipGraph.  AUTO picks DEVICE for launches of up to 4096 workgroups of the tile
  * kernels (where an event pair would measure mostly itself: the reference's own sample matrices), else EVENTS. */
-enum { SMVP_TIMING_AUTO = 0, SMVP_TIMING_EVENTS = 1, SMVP_TIMING_DEVICE = 2 };
+enum { SMVP_TIMING_AUTO = 0, SMVP_TIMING_EVENTS = 1, SMVP_TIMING_DEVICE = 2,
+       SMVP_TIMING_DEVICE_GRAPH = 3 /* DEVICE, but one launch per product replayed from a hipGraph: what DEVICE falls back to */ };
 typedef struct smvp_run_info {
-    int timing;            /* SMVP_TIMING_EVENTS or SMVP_TIMING_DEVICE: what the last smvp_*_compute on this thread used */
+    int timing;            /* SMVP_TIMING_EVENTS or SMVP_TIMING_DEVICE (also for DEVICE_GRAPH: repeat_launches / graph_replays tell the
+                              form): what the last smvp_*_compute on this thread used */
     int graph_replays;     /* hipGraph launches it took (0 = plain launches) */
     double wall_ms;        /* host wall time of the whole timed loop, launches, timing and waits included */
     double device_clock_khz; /* DEVICE: rate of the clock the times were taken with */

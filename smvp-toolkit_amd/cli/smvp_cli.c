@@ -20,7 +20,7 @@
  *   - libpopt is not used (absent from the image): getopt_long("+...") gives the
  *     same POSIX ordering rule.
  * Additive flags: --device N, --gpus N, --iterate, --normalize, --ref-quirks, --device-convert, --csr-kernel auto|vector|stream|stream-carry|colsweep|binned,
- * --tjds-mode auto|row-gather|two-phase|atomic, --timing auto|events|device, --expand-symmetric, --cache,
+ * --tjds-mode auto|row-gather|two-phase|atomic, --timing auto|events|device|device-graph, --expand-symmetric, --cache,
  * --x ones|random, --dump-arrays.  The reference's shipped binary prints whole arrays (SMVP_CSR_DEBUG 1,
  * main-cli.c:10,374-394,458-466,1166-1191); here those dumps -- and the TJDS ones its source holds behind
  * SMVP_TJDS_DEBUG (main-cli.c:870-892,969-992,1150-1158) -- are printed only with --dump-arrays.
@@ -53,7 +53,7 @@ static void usage(FILE *to, const char *prog)
             "Usage: %s [-acgt?] [-a|--all-algs] [-c|--csr] [-g|--cisr-gen] [-t|--tjds]\n"
             "        [-n|--number=1000] [-s|--slots=16] [-d|--dir=./] [--device=0] [--gpus=1] [--exchange=auto] [--virtual-gpus]\n"
             "        [--ref-quirks] [--iterate] [--normalize] [--device-convert] [--csr-kernel=auto|vector|stream|stream-carry|colsweep|binned]\n"
-            "        [--tjds-mode=auto|row-gather|two-phase|atomic] [--timing=auto|events|device]\n"
+            "        [--tjds-mode=auto|row-gather|two-phase|atomic] [--timing=auto|events|device|device-graph]\n"
             "        [--expand-symmetric] [--cache] [--x=ones|random] [--dump-arrays]\n"
             "        [-?|--help] [--usage]\n"
             "        [OPTIONS] <file>\n",
@@ -83,7 +83,8 @@ static void help(const char *prog)
     puts("      --device-convert     Build CSR / TJDS from the loaded entries on the GPU instead of the host.");
     puts("      --csr-kernel=auto    CSR kernel family: auto, vector, stream, stream-carry, colsweep, binned.");
     puts("      --tjds-mode=auto     TJDS product: auto (= row-gather, one kernel), two-phase, atomic.");
-    puts("      --timing=auto        Per-product window: events (hipEvent pair), device (the kernel times itself), auto.");
+    puts("      --timing=auto        Per-product window: events (hipEvent pair), device (the kernel times itself; up to 1024");
+    puts("                           products per launch), device-graph (the same stamps, one launch per product), auto.");
     puts("      --expand-symmetric   Mirror the stored triangle of a symmetric file (the reference multiplies it as stored).");
     puts("      --cache              Keep / use <file>.smvpbin, a binary copy of the loaded matrix tied to the file's checksum.");
     puts("      --x=ones             Operand: ones (the reference's) or random (uniform [0, 1), seed 67890).");
@@ -400,8 +401,10 @@ int main(int argc, char *argv[])
                 timing = SMVP_TIMING_EVENTS;
             else if (strcmp(optarg, "device") == 0)
                 timing = SMVP_TIMING_DEVICE;
+            else if (strcmp(optarg, "device-graph") == 0)
+                timing = SMVP_TIMING_DEVICE_GRAPH;
             else
-                die("Unknown timing method (use auto, events or device).");
+                die("Unknown timing method (use auto, events, device or device-graph).");
             break;
         case OPT_TJDS_MODE:
             if (strcmp(optarg, "auto") == 0)

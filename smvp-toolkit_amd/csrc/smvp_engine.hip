@@ -1606,7 +1606,7 @@ int check_iterate(const smvp_run_opts_t *o, int rows, int cols)
                           o->struct_size, (unsigned)sizeof(smvp_run_opts_t));
     if (o->iterate && rows != cols)
         return smvp::fail(SMVP_ERR_INVALID, "power iteration needs a square matrix (%d x %d given)", rows, cols);
-    if (o->timing < SMVP_TIMING_AUTO || o->timing > SMVP_TIMING_DEVICE)
+    if (o->timing < SMVP_TIMING_AUTO || o->timing > SMVP_TIMING_DEVICE_GRAPH)
         return smvp::fail(SMVP_ERR_INVALID, "unknown timing method %d", o->timing);
     return SMVP_OK;
 }
@@ -1651,15 +1651,16 @@ struct StampTimer {
 // `iters` products on s.stream, each timed on its own.  pre(y): work the reference keeps outside its window (clearing
 // y); product(x, y, stamps): the launches of one product.  stamp_slots > 0: the product can time itself on the device.
 // repeat_grid > 0: the product has a repeating form -- repeat(x, y, stamps, reps, grid, ctl_words) enqueues `reps` products as
-// ONE launch that stamps every product's window (needs no `pre`); used for device-timed runs unless SMVP_NO_PERSIST is set.
+// ONE launch that stamps every product's window (needs no `pre`); used for device-timed runs unless SMVP_TIMING_DEVICE_GRAPH asks
+// for one launch per product.
 template <class Pre, class Product, class Repeat>
 int run_timed_products(RunScratch &s, int rows, int iters, const smvp_run_opts_t *o, int stamp_slots, Pre pre, Product product,
                        int repeat_grid, Repeat repeat)
 {
     double *xc = s.d_x, *yc = s.d_y;
-    const bool stamped = o->timing != SMVP_TIMING_EVENTS && !o->iterate && stamp_slots > 0 &&
-                         (o->timing == SMVP_TIMING_DEVICE || stamp_slots <= kStampMaxSlots);
-    if (o->timing == SMVP_TIMING_DEVICE && !stamped)
+    const bool device_asked = o->timing == SMVP_TIMING_DEVICE || o->timing == SMVP_TIMING_DEVICE_GRAPH;
+    const bool stamped = o->timing != SMVP_TIMING_EVENTS && !o->iterate && stamp_slots > 0 && (device_asked || stamp_slots <= kStampMaxSlots);
+    if (device_asked && !stamped)
         return smvp::fail(SMVP_ERR_UNSUPPORTED, "device-side timing needs the tile kernel of one GPU and no --iterate");
     g_last_run.timing = stamped ? SMVP_TIMING_DEVICE : SMVP_TIMING_EVENTS;
     g_last_run.graph_replays = 0;
@@ -1676,7 +1677,7 @@ int run_timed_products(RunScratch &s, int rows, int iters, const smvp_run_opts_t
             return smvp::fail(SMVP_ERR_HIP, "the device reports no wall-clock rate");
         g_last_run.device_clock_khz = khz;
     }
-    if (stamped && repeat_grid > 0 && getenv("SMVP_NO_PERSIST") == nullptr) {  // (development switch: read at the start of a run)
+    if (stamped && repeat_grid > 0 && o->timing != SMVP_TIMING_DEVICE_GRAPH) {
         // Up to kRepeatRing products per launch of the repeating kernel, the launches of a run enqueued one behind the other:
         // every launch's windows are reduced on the device into first_last[product] and its give-up word is set aside; the
         // host waits once per kRepeatSuper products.  A launch that gave up at one of its barriers (the grid was not resident
@@ -1817,7 +1818,7 @@ extern "C" int smvp_last_run_info(smvp_run_info_t *out)
 static int sharded_compute(bool tjds, const smvp_coo_t *coo, int rows, int cols, int nnz, int iters,
                            const smvp_run_opts_t *o, double *y, double *time_each_ms, smvp_time_stats_t *stats)
 {
-    if (o->timing == SMVP_TIMING_DEVICE)  // the in-kernel stamps time one launch of one GPU; a sharded product is several
+    if (o->timing == SMVP_TIMING_DEVICE || o->timing == SMVP_TIMING_DEVICE_GRAPH)  // the in-kernel stamps time one launch of one GPU; a sharded product is several
         return smvp::fail(SMVP_ERR_UNSUPPORTED, "device-side timing is not available with more than one GPU (use events)");
     smvp_sharded_t *h = nullptr;
     smvp_shard_opts_t so;

@@ -24,7 +24,7 @@ CSR_KERNEL_BINNED = 5
 MEM_HOST, MEM_DEVICE = 0, 1
 SYNTH_MEMPLUS_SHAPED, SYNTH_UNIFORM = 1, 2
 TJDS_MODE_AUTO, TJDS_MODE_ATOMIC, TJDS_MODE_TWO_PHASE, TJDS_MODE_ROW_GATHER = 0, 1, 2, 3
-TIMING_AUTO, TIMING_EVENTS, TIMING_DEVICE = 0, 1, 2
+TIMING_AUTO, TIMING_EVENTS, TIMING_DEVICE, TIMING_DEVICE_GRAPH = 0, 1, 2, 3
 
 COO_DTYPE = np.dtype([("row", "<i4"), ("col", "<i4"), ("val", "<f8")], align=True)
 

@@ -1969,9 +1969,9 @@ def test_many_iterations_use_the_timing_rings(torch, timing):
     assert ob.fmt_g(y) == ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_1615284655.txt"))
 
 
-def test_device_timing_agrees_with_events_and_is_the_default_for_small_launches(torch, monkeypatch):
+def test_device_timing_agrees_with_events_and_is_the_default_for_small_launches(torch):
     """The reference's window holds the product only (main-cli.c:408-419).  On its own sample matrices the kernel times
-    itself (wall-clock stamps per wave; up to 1024 products per launch of the repeating kernel, or -- SMVP_NO_PERSIST -- one
+    itself (wall-clock stamps per wave; up to 1024 products per launch of the repeating kernel, or -- TIMING_DEVICE_GRAPH -- one
     launch per product replayed from a hipGraph); a hipEvent pair around the same launch can only read longer (it includes
     the launch and the events), and never by more than a few launch overheads.  Every form gives the same y."""
     m, n, coo = load("memplus.mtx")
@@ -1982,10 +1982,8 @@ def test_device_timing_agrees_with_events_and_is_the_default_for_small_launches(
         assert info.wall_ms >= st_d.time_total * 0.5 and len(ms_d) == 300 and np.all(ms_d > 0)
         # the windows of one launch cannot overlap: their sum is at most the loop's wall time
         assert st_d.time_total <= info.wall_ms
-        monkeypatch.setenv("SMVP_NO_PERSIST", "1")
-        y_g, ms_g, st_g = fn(coo, m, n, iters=300)
+        y_g, ms_g, st_g = fn(coo, m, n, iters=300, timing=sm.TIMING_DEVICE_GRAPH)
         info_g = sm.last_run_info()
-        monkeypatch.delenv("SMVP_NO_PERSIST")
         assert info_g.timing == sm.TIMING_DEVICE and info_g.graph_replays == 2 and info_g.repeat_launches == 0
         assert np.array_equal(y_d, y_g)
         assert st_d.time_avg <= st_g.time_avg * 1.25                       # warm caches, no dispatch ramp: not slower than a launch of its own
