@@ -1219,6 +1219,8 @@ hipError_t launch_csr_stream_owner_repeat(int vpt, int flavor, const OwnerLaunch
     // arrivals cost about 12 ns each on one address: n / S on a shard, then S on the top counter
     // measured (profiles/r05_cli_n1000.txt): one level up to two dozen workgroups, 8 shards up to ~600, 16 beyond
     ctl.shards = grid <= 24 ? 1 : grid <= 640 ? 8 : 16;
+    ctl.stamps = l.stamps;
+    ctl.reps = reps, ctl.grid_virtual = (int)owner_grid(l.ntiles, group), ctl.slots_per_product = grid * (kStreamBlock / 64);
 #define X(V, F)                                                                                                                    \
     if (vpt == V && flavor == F) {                                                                                                 \
         hipLaunchKernelGGL((csr_stream_owner_repeat<V, F>), dim3((unsigned)grid), dim3(kStreamBlock), 0, stream, l.row_ptr, l.col_ind, \
