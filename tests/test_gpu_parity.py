@@ -1250,7 +1250,8 @@ def test_bench_starts_its_own_ranks(torch):
         assert key in r, key
     assert "config4_c_layer_error" not in r, r.get("config4_c_layer_error")
     assert r["config4_c_layer_overlapped_ms_1chunk"] > 0 and r["exchange_direct_ms"] > 0
-    left = [q for q in psutil.process_iter(["cmdline"]) if q.pid not in before and "bench.py" in " ".join(q.info["cmdline"] or [])]
+    left = [q for q in psutil.process_iter(["cmdline", "name"]) if q.pid not in before and "python" in (q.info["name"] or "")
+            and "bench.py" in " ".join(q.info["cmdline"] or [])]      # (python processes only: a shell's command line may name bench.py too)
     assert not left, left
 
 
