@@ -60,7 +60,7 @@ def main():
     import smvp_toolkit_amd as sm
     import oracle_binding as ob
     csr_variants = [(sm.CSR_KERNEL_STREAM, p) for p in (256, 1024, 2048)] + [(sm.CSR_KERNEL_STREAM_CARRY, p) for p in (1024, 2048)] + \
-                   [(sm.CSR_KERNEL_VECTOR, p) for p in (2, 16, 64)] + [(sm.CSR_KERNEL_COLSWEEP, p) for p in (0, 1024, 8192)] + \
+                   [(sm.CSR_KERNEL_VECTOR, p) for p in (2, 16, 64)] + [(sm.CSR_KERNEL_COLSWEEP, p) for p in (0, 1024, 8192, 300, 1028)] + \
                    [(sm.CSR_KERNEL_BINNED, p) for p in (0, 1, 7, 100)]
     bad = 0
     for seed in range(a.seeds):
@@ -120,10 +120,13 @@ def main():
                 check(dy.cpu().numpy()[:rows], "tjds mode %d" % mode)
             T.close()
         del os.environ["SMVP_TJDS_INDEX"]
-        y, _, _ = sm.csr_compute(coo, rows, cols, iters=3, x=x)
+        y, _, _ = sm.csr_compute(coo, rows, cols, iters=3, x=x)        # (device-timed: the repeating kernel, three products in one launch)
         check(y, "csr_compute")
         y, _, _ = sm.tjds_compute(coo, rows, cols, iters=3, x=x, device_convert=True)
         check(y, "tjds_compute (device conversion)")
+        if rows > 0:
+            y, _, _ = sm.csr_compute(coo, rows, cols, iters=2, x=x, timing=sm.TIMING_DEVICE_GRAPH if seed % 2 else sm.TIMING_EVENTS)
+            check(y, "csr_compute, other timing forms")
         if seed % 50 == 49:
             print("... %d seeds, %d mismatches" % (seed + 1, bad), flush=True)
     print("done: %d seeds, %d mismatches" % (a.seeds, bad))
