@@ -9,7 +9,7 @@ constexpr int kStreamBlock = 256;   // threads per block, csr_stream_tiles
 constexpr int kLongRow = 32;        // segments longer than this are summed by a wavefront
 constexpr int kStreamOver = 1024;    // entries past its end a tile may finish its last row with, through LDS
 constexpr int kStreamTileGroup = 64;  // consecutive tiles per XCD turn (see tile_of_block)
-constexpr int kTjdsTileGroup = 16;    // ... for the tile-ordered TJDS stream
+constexpr int kTjdsTileGroup = 32;    // ... for the tile-ordered TJDS stream (16 until round 5)
 constexpr int kSweepBlock = 256;   // threads per block, csr_colsweep: four wavefronts, each with its own strip of rows
 constexpr int kSweepWaves = kSweepBlock / 64;
 constexpr int kSweepUnroll = 4;    // stream entries per lane and pass: a wavefront takes its strip 256 entries at a time

@@ -1095,9 +1095,11 @@ hipError_t launch_csr_stream(int vpt, const int *row_ptr, const int *col_ind, co
 // grid of a launch of `ntiles` tiles (a multiple of 8 * group, see tile_of_block)
 static unsigned owner_grid(int ntiles, int group) { return (unsigned)((ntiles + 8 * group - 1) / (8 * group)) * 8u * group; }
 
-// tiles per XCD turn by flavour: the tile-ordered TJDS stream re-uses val lines between neighbouring tiles and does
-// best when an XCD comes back to a neighbourhood soon (measured on memplus x944, 2048-entry tiles: group 16 / 32 /
-// 64 / 128 -> 0.592 / 0.596 / 0.612 / 0.601 ms); CSR measured best at 64 (profiles/r01_tile_group_sweep.txt)
+// tiles per XCD turn by flavour.  CSR measured best at 64 (profiles/r01_tile_group_sweep.txt).  The tile-ordered TJDS stream: the
+// group decides how often x_perm crosses the fabric -- a copy of memplus is 61 tiles, every XCD that gets some of them pulls
+// the copy's part of x_perm -- but not the time (round 5, memplus x944, PMC FETCH per product / ms; x_perm's share in brackets):
+// group 4: 2125 MB (388)   16: 2059 (333) 0.390   32: 1983 (258) 0.391   48: 1934 (211) 0.392   64: 1907 (185) 0.395   256: 1841 (126)
+// pwt x459: 0.263-0.267 / 0.265-0.267 / 0.267-0.268 / 0.269-0.270 ms for 16 / 32 / 48 / 64.  32 moves 76 MB less at the same speed.
 static int flavor_group(int flavor) { return flavor == kFlavorTjdsS || flavor == kFlavorTjdsH ? kTjdsTileGroup : kStreamTileGroup; }
 
 int owner_stamp_slots(int ntiles, int flavor)
