@@ -1159,9 +1159,12 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
 }
 
 // ---- the repeating form (csr_stream_owner_repeat): `reps` products in one launch
-// Workgroups of the repeating launch for a plan of `ntiles` tiles: the plain launch's grid, capped so that the whole grid is
-// resident at once with room to spare (the occupancy query can read one workgroup per CU high, MI355X_MICROARCH "Residency");
-// 0: this (vpt, flavor) has no repeating form, or the device could not be asked.
+// Workgroups of the repeating launch for a plan of `ntiles` tiles: the plain launch's grid -- every workgroup its one tile per
+// product, as in a launch of its own -- if that grid is resident at once with room to spare (the occupancy query can read one
+// workgroup per CU high, MI355X_MICROARCH "Residency"); 0: the grid is larger (a capped grid whose workgroups walk several tiles
+// per product runs each product slower than a launch of its own does -- memplus x2 ... x32: windows of 4.8 ... 17.9 us against
+// 3.3 ... 12.8, profiles/r05_cli_n1000.txt -- so those matrices keep one launch per product), this (vpt, flavor) has no repeating
+// form, or the device could not be asked.
 template <int V, int F>
 static int repeat_capacity()
 {
@@ -1171,7 +1174,7 @@ static int repeat_capacity()
         (void)hipGetLastError();
         return 0;
     }
-    return per_cu > 1 ? (per_cu - 1) * cus / 2 : 0;  // half of (one workgroup per CU fewer than the query's answer)
+    return per_cu > 1 ? (per_cu - 1) * cus * 3 / 4 : 0;  // three quarters of (one workgroup per CU fewer than the query's answer)
 }
 
 #define SMVP_REPEAT_FORMS(X) \
@@ -1191,7 +1194,7 @@ int owner_repeat_grid(int vpt, int flavor, int ntiles)
     if (cap <= 0)
         return 0;
     const int full = (int)owner_grid(ntiles, tile_group(ntiles, flavor_group(flavor)));
-    return full < cap ? full : cap;
+    return full <= cap ? full : 0;
 }
 
 // `reps` products, each stamped: stamps[reps][grid * 4][2]; ctl_words: kRepeatCtlWords unsigned, cleared here.
