@@ -1217,7 +1217,7 @@ def test_bench_script_runs_small(torch):
                 "config4_c_layer_products_only_ms_1chunk", "config4_c_layer_overlapped_ms_1chunk", "config4_c_layer_after_ms_4chunk",
                 "exchange_rccl_ms", "exchange_copies_ms", "exchange_direct_ms", "c_layer_exchange_chosen",
                 "memplus_csr_us", "memplus_tjds_us", "memplus_csr_loop_wall_us", "pwt_csr_us", "config5_csr_us", "config5_both_us",
-                "exchange", "dist_backend", "rccl_ranks", "n_gpus", "self_launched"):
+                "exchange", "dist_backend", "rccl_ranks", "n_gpus", "self_launched", "prewarm_ms"):
         assert key in r and not isinstance(r[key], (dict, list)), key
     assert r["frac_tjds"] == o["tjds"]["frac"] and r["frac_config4"] == o["config4"]["frac"] and r["rccl_ranks"] == 0
     assert r["config4_t1_ms"] == o["config4"]["t1_ms"] and r["config4_speedup_overlapped"] == 1.0 and r["self_launched"] is False
