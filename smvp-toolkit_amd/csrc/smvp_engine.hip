@@ -147,6 +147,9 @@ struct smvp_csr {
     // offsets from the tile's smallest column (10 instead of 12 bytes per entry; csr_stream_owner<., kFlavorCsr16, .>)
     unsigned short *d_col16 = nullptr;
     int *d_col_base = nullptr;
+    // STREAM with tiles of 1024 / 2048 entries: every row's first entry as a 16-bit offset from the first entry of the tile the row
+    // starts in -- what phase 2 reads instead of row_ptr (2 instead of 4 bytes per row)
+    unsigned short *d_row_rel = nullptr;
     bool tile_chosen = false;     // the caller named the tile size (smvp_csr_set_kernel param): the plan keeps it
     int *d_carry_row = nullptr;   // STREAM_CARRY
     double *d_carry = nullptr;    // STREAM_CARRY
@@ -382,8 +385,11 @@ void free_stream_plan(smvp_csr *h)
         (void)hipFree(h->d_col16);
     if (h->d_col_base)
         (void)hipFree(h->d_col_base);
+    if (h->d_row_rel)
+        (void)hipFree(h->d_row_rel);
     h->d_col16 = nullptr;
     h->d_col_base = nullptr;
+    h->d_row_rel = nullptr;
     for (void *p : {(void *)h->d_pos_sorted, (void *)h->d_meta, (void *)h->d_ovf_ptr, (void *)h->d_ovf_val, (void *)h->d_ovf_k,
                     (void *)h->d_cache_ptr, (void *)h->d_val_cache, (void *)h->d_meta16, (void *)h->d_group_run,
                     (void *)h->d_run_ptr, (void *)h->d_run_sp})
@@ -463,6 +469,16 @@ int build_stream_plan(smvp_csr *h)
     if (h->kernel == SMVP_CSR_KERNEL_STREAM) {
         if (int rc = upload(&h->d_tile_next, tile_next))
             return rc;
+        if (tile >= 1024 && h->rows > 0 && getenv("SMVP_CSR_ROWREL") == nullptr) {  // (development switch, plan time: set = keep row_ptr)
+            std::vector<unsigned short> rel((size_t)h->rows);
+            for (int b = 0; b < ntiles; ++b) {
+                const long long s0 = (long long)b * tile;
+                for (int rr = tile_row[(size_t)b]; rr < tile_row[(size_t)b + 1]; ++rr)
+                    rel[(size_t)rr] = (unsigned short)(rp[rr] - s0);  // 0 ... tile (tile: trailing rows without entries)
+            }
+            if (int rc = upload(&h->d_row_rel, rel))
+                return rc;
+        }
     } else {
         if (int rc = upload(&h->d_carry_row, carry_row))
             return rc;
@@ -828,6 +844,7 @@ static void fill_owner_launch(const smvp_csr_t *h, const double *d_x, double *d_
     l.stamps = stamps;
     l.rows = h->rows, l.nnz = h->nnz, l.ntiles = h->ntiles;
     l.col16 = h->d_col16, l.col_base = h->d_col_base;
+    l.row_rel = h->d_row_rel;
 }
 
 // `reps` products of the tile kernel in ONE launch, each product's window stamped (csr_stream_owner_repeat); grid from
@@ -1003,6 +1020,8 @@ static double csr_plan_bytes(const smvp_csr_t *h)
         b += 8.0 * t;
     if (h->d_col16)
         b += 2.0 * n + 4.0 * (n / 1024 + 1);
+    if (h->d_row_rel)
+        b += 2.0 * h->rows;
     if (h->flavor == smvp::kFlavorTjdsS || h->flavor == smvp::kFlavorTjdsH) {
         b += 4.0 * n + 4.0 * (t + 1) + 12.0 * h->ovf_total + 4.0 * (t + 2) + 8.0 * h->cached_total;
         b += h->flavor == smvp::kFlavorTjdsH ? 2.0 * n + 4.0 * (t + 2) + 4.0 * h->runs_total + 2.0 * (n / 32 + 1) : 4.0 * n;

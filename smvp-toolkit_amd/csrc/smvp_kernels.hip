@@ -238,6 +238,8 @@ struct OwnerExtra {
     const unsigned short *group_run;  // TjdsH: per tile and group of 32 entries, the run (inside the tile) of its first entry
     const int *run_ptr;             // TjdsH: ntiles + 1 bounds of the tiles' runs in run_sp
     const int *run_sp;              // TjdsH: start_pos of every run's diagonal (0 for a tile's run of cached entries)
+    const unsigned short *row_rel;  // tiles of 1024 / 2048 entries: every row's first entry relative to the first entry of the tile it
+                                    // starts in (2 B per row read by the product instead of row_ptr's 4); nullptr: row_ptr itself
     unsigned long long *stamps;     // STAMPED: per-wave {first, last} wall-clock ticks of this launch
     int stream_nt;                  // TjdsS: load the pos / slot streams non-temporally (development switch)
 };
@@ -464,13 +466,25 @@ __device__ __forceinline__ void owner_body(
     const int e = (int)(s + TILE < (long long)nnz ? s + TILE : (long long)nnz);
     const int zend = tile_next[b];  // row_ptr[rhi]: end of the last owned row, >= e
     const int ext = zend - e;
+    // bounds of owned row r as offsets from the tile's first entry: from the plan's 16-bit offsets where it keeps them (the
+    // last owned row ends at zend), else from row_ptr
+    const unsigned short *__restrict__ row_rel = ex.row_rel;
+    auto row_bounds = [&](int r, int &ra, int &rz) {
+        if (row_rel) {
+            ra = row_rel[r];
+            rz = r + 1 < rhi ? (int)row_rel[r + 1] : zend - lo;
+        } else {
+            ra = row_ptr[r] - lo;
+            rz = row_ptr[r + 1] - lo;
+        }
+    };
     const bool giant = ext > kStreamOver;
     if (t == 0)
         long_count = 0;
     const bool over0 = !giant && t < ext;  // this lane fetches overflow entry e + t
     double p[VPT];
     double po = 0.0;
-    int rp_a = 0, rp_b = 0, rp_a2 = 0, rp_b2 = 0;  // bounds of this lane's first two rows of phase 2 (rlo + t, rlo + t + 256)
+    int rp_a = 0, rp_b = 0, rp_a2 = 0, rp_b2 = 0;  // bounds of this lane's first two rows of phase 2 (rlo + t, rlo + t + 256), from the tile's first entry
     int ovf_base = 0, cache0 = 0, in_place = 0;
     if constexpr (SORTED) {
         ovf_base = ex.ovf_ptr[b];
@@ -478,14 +492,10 @@ __device__ __forceinline__ void owner_body(
         in_place = (e - lo) - (ex.cache_ptr[b + 1] - cache0);  // entries of this tile whose value is read from val itself
     }
     if constexpr (SORTED) {
-        if (full_tile && rlo + t < rhi) {
-            rp_a = row_ptr[rlo + t];
-            rp_b = row_ptr[rlo + t + 1];
-        }
-        if (full_tile && rlo + t + kStreamBlock < rhi) {
-            rp_a2 = row_ptr[rlo + t + kStreamBlock];
-            rp_b2 = row_ptr[rlo + t + kStreamBlock + 1];
-        }
+        if (full_tile && rlo + t < rhi)
+            row_bounds(rlo + t, rp_a, rp_b);
+        if (full_tile && rlo + t + kStreamBlock < rhi)
+            row_bounds(rlo + t + kStreamBlock, rp_a2, rp_b2);
         int co = 0;
         double vo = 0.0;
         if (over0 && !(SMVP_TJDS_NEUTRALISE & 8)) {
@@ -549,14 +559,12 @@ __device__ __forceinline__ void owner_body(
                 po = vo * a.x[co];
         }
     } else if (whole) {
-        if (rlo + t < rhi) {  // this lane's first row in phase 2
-            rp_a = row_ptr[rlo + t];
-            rp_b = row_ptr[rlo + t + 1];
-        }
-        if (rlo + t + kStreamBlock < rhi) {  // ... and its second: with short rows a tile holds more rows than lanes, and a
-            rp_a2 = row_ptr[rlo + t + kStreamBlock];  // row_ptr read behind the barrier is a whole memory round trip in phase 2
-            rp_b2 = row_ptr[rlo + t + kStreamBlock + 1];  // (in-kernel stamps on the near part of the random model, 4.3
-        }                                                 // entries per row: phase 2 took 4.1 of the workgroup's 9.9 us)
+        if (rlo + t < rhi)  // this lane's first row in phase 2
+            row_bounds(rlo + t, rp_a, rp_b);
+        if (rlo + t + kStreamBlock < rhi)  // ... and its second: with short rows a tile holds more rows than lanes, and a row_ptr read
+            row_bounds(rlo + t + kStreamBlock, rp_a2, rp_b2);  // behind the barrier is a whole memory round trip in phase 2 (in-kernel
+                                                               // stamps on the near part of the random model, 4.3 entries per row:
+                                                               // phase 2 took 4.1 of the workgroup's 9.9 us)
         int co = 0, pjo = 0;
         double vo = 0.0;
         if (over0) {
@@ -645,16 +653,18 @@ __device__ __forceinline__ void owner_body(
     int r_next = rlo + t;
     if (full_tile) {
         if (r_next < rhi && !(giant && r_next == last))
-            finish_row(r_next, rp_a - lo, rp_b - lo);
+            finish_row(r_next, rp_a, rp_b);
         r_next += kStreamBlock;
         if (r_next < rhi && !(giant && r_next == last))
-            finish_row(r_next, rp_a2 - lo, rp_b2 - lo);
+            finish_row(r_next, rp_a2, rp_b2);
         r_next += kStreamBlock;
     }
     for (int r = r_next; r < rhi; r += kStreamBlock) {
         if (giant && r == last)
             continue;
-        finish_row(r, row_ptr[r] - lo, row_ptr[r + 1] - lo);
+        int ra, rz;
+        row_bounds(r, ra, rz);
+        finish_row(r, ra, rz);
     }
     SMVP_PHASE(3);
     __syncthreads();
@@ -1125,6 +1135,7 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
     ex.col16 = l.col16, ex.col_base = l.col_base;
     ex.meta16 = l.meta16, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_sp = l.run_sp;
     ex.stamps = l.stamps, ex.stream_nt = nt;
+    ex.row_rel = l.row_rel;
 #define SMVP_OWNER_ST(V, F, S)                                                                                     \
     hipLaunchKernelGGL((csr_stream_owner<V, F, S>), grid, dim3(kStreamBlock), 0, stream, l.row_ptr, l.col_ind, l.val, \
                        l.x, l.y, l.tile_row, l.tile_next, l.rows, l.nnz, l.ntiles, group, ex)
@@ -1219,6 +1230,7 @@ hipError_t launch_csr_stream_owner_repeat(int vpt, int flavor, const OwnerLaunch
     ex.col16 = l.col16, ex.col_base = l.col_base;
     ex.meta16 = l.meta16, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_sp = l.run_sp;
     ex.stamps = nullptr, ex.stream_nt = nt;
+    ex.row_rel = l.row_rel;
     RepeatCtl ctl;
     ctl.shard = ctl_words, ctl.go = ctl_words + 32 * kRepeatMaxShards, ctl.top = ctl_words + kRepeatCtlWords - 32;
     // arrivals cost about 12 ns each on one address: n / S on a shard, then S on the top counter
