@@ -201,7 +201,7 @@ template <int SLOTS, int THREADS, int G>
 __global__ __launch_bounds__(THREADS) void csr_binned_far_sums(
     const double *__restrict__ bins, const unsigned short *__restrict__ b_word, const int *__restrict__ b_chunk,
     const int4 *__restrict__ b_desc, const int *__restrict__ b_shift, const int *__restrict__ fr_row,
-    const int *__restrict__ fr_ptr, double *__restrict__ y, int nrb, int q)
+    const int *__restrict__ fr_ptr, const unsigned *__restrict__ fr32, double *__restrict__ y, int nrb, int q)
 {
     extern __shared__ double lds[];  // all of it dynamic: the products' slots come first, 8-byte aligned
 #ifdef SMVP_PHASE_STAMPS
@@ -229,6 +229,7 @@ __global__ __launch_bounds__(THREADS) void csr_binned_far_sums(
     const int k0 = d0.z, k1 = d0.w;    // its far rows
     const int f0 = d1.x;               // its first far entry: slots count from it
     const int sp = d1.y, nruns = d1.z; // its sub-runs' shifts
+    const int row_base = d1.w;         // fr32: the block's first far row (the list holds 16-bit offsets from it)
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);  // (uniform: the chunk counts become scalar loads)
     const unsigned long long le = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1);
     // Everything that hangs on the scalars above goes out together, ahead of the one barrier the shifts need: the sub-runs'
@@ -261,9 +262,16 @@ __global__ __launch_bounds__(THREADS) void csr_binned_far_sums(
         const int k = k0 + u * THREADS + t;
         prow[u] = -1, pa[u] = 0, pz[u] = 0;
         if (k < k1) {
-            prow[u] = fr_row[k];
-            pa[u] = fr_ptr[k] - f0;
-            pz[u] = fr_ptr[k + 1] - f0;
+            if (fr32) {  // one word per far row: row - row_base | first slot << 16; the row ends where the next begins (a sentinel
+                const unsigned w0 = fr32[k + rb], w1 = fr32[k + rb + 1];  // per block: hence the + rb)
+                prow[u] = row_base + (int)(w0 & 0xffffu);
+                pa[u] = (int)(w0 >> 16);
+                pz[u] = (int)(w1 >> 16);
+            } else {
+                prow[u] = fr_row[k];
+                pa[u] = fr_ptr[k] - f0;
+                pz[u] = fr_ptr[k + 1] - f0;
+            }
         }
     }
     for (int i = t; i < nruns && i < kBinShiftCap; i += THREADS)
@@ -334,7 +342,13 @@ __global__ __launch_bounds__(THREADS) void csr_binned_far_sums(
         }
     }
     for (int k = k0 + kBinPre * THREADS + t; k < k1; k += THREADS) {
-        const int r = fr_row[k], ra = fr_ptr[k] - f0, rz = fr_ptr[k + 1] - f0;
+        int r, ra, rz;
+        if (fr32) {
+            const unsigned w0 = fr32[k + rb], w1 = fr32[k + rb + 1];
+            r = row_base + (int)(w0 & 0xffffu), ra = (int)(w0 >> 16), rz = (int)(w1 >> 16);
+        } else {
+            r = fr_row[k], ra = fr_ptr[k] - f0, rz = fr_ptr[k + 1] - f0;
+        }
         const double yr = y[r];
         if (rz - ra <= kBinLongRow) {
             y[r] = yr + row_sum(ra, rz);
@@ -594,15 +608,42 @@ __global__ __launch_bounds__(256) void bin_emit(const u64 *__restrict__ key, con
 
 // b_desc[2 * rb] = {a, z, k0, k1}, b_desc[2 * rb + 1] = {f0, sp, nruns, 0}: what a workgroup of pass B reads first
 __global__ __launch_bounds__(256) void bin_block_desc(const int *__restrict__ b_ptr, const int *__restrict__ b_shift_ptr,
-                                                      const int *__restrict__ blk_fr, const int *__restrict__ fr_ptr, int nrb,
-                                                      int4 *__restrict__ desc)
+                                                      const int *__restrict__ blk_fr, const int *__restrict__ fr_ptr,
+                                                      const int *__restrict__ fr_row, int nrb, int4 *__restrict__ desc)
 {
     const int rb = blockIdx.x * 256 + threadIdx.x;
     if (rb >= nrb)
         return;
     const int k0 = blk_fr[rb], k1 = blk_fr[rb + 1], sp = b_shift_ptr[rb];
     desc[2 * rb] = make_int4(b_ptr[rb], b_ptr[rb + 1], k0, k1);
-    desc[2 * rb + 1] = make_int4(fr_ptr[k0], sp, b_shift_ptr[rb + 1] - sp, 0);
+    desc[2 * rb + 1] = make_int4(fr_ptr[k0], sp, b_shift_ptr[rb + 1] - sp, k1 > k0 ? fr_row[k0] : 0);
+}
+
+// The far rows' list as pass B reads it: one 32-bit word per far row -- (row - the block's first far row) | (first slot << 16) --
+// and one sentinel per block carrying the block's entry count, so that a row ends where the next word begins: entry k of
+// block rb sits at k + rb.  *bad is set when a block's rows span 65536 or more (the 32-bit lists stay in use then).
+__global__ __launch_bounds__(256) void bin_far_rows_packed(const int *__restrict__ fr_row, const int *__restrict__ fr_ptr,
+                                                           const int *__restrict__ blk_fr, int nfr, int nrb,
+                                                           unsigned *__restrict__ fr32, int *__restrict__ bad)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nfr)
+        return;
+    int lo = 0, hi = nrb - 1;  // the block of far row k: last rb with blk_fr[rb] <= k
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (blk_fr[mid] <= k)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const int rb = lo, k0 = blk_fr[rb], k1 = blk_fr[rb + 1];
+    const int rel = fr_row[k] - fr_row[k0], slot = fr_ptr[k] - fr_ptr[k0];
+    if (rel > 0xffff || slot > 0xffff)
+        atomicExch(bad, 1);
+    fr32[k + rb] = (unsigned)(rel & 0xffff) | ((unsigned)(slot & 0xffff) << 16);
+    if (k == k1 - 1)
+        fr32[k1 + rb] = (unsigned)((fr_ptr[k1] - fr_ptr[k0]) & 0xffff) << 16;
 }
 
 int scan_exclusive(const int *in, int *out, size_t n, Scratch &sc, hipStream_t st)
@@ -702,7 +743,7 @@ void free_binned_plan(BinnedPlan *p)
     if (!p)
         return;
     for (void *q : {(void *)p->near_ptr, (void *)p->near_col, (void *)p->near_val, (void *)p->a_val, (void *)p->bins, (void *)p->fr_row,
-                    (void *)p->fr_ptr, (void *)p->blk_fr, (void *)p->b_desc})
+                    (void *)p->fr_ptr, (void *)p->blk_fr, (void *)p->b_desc, (void *)p->fr32})
         if (q)
             (void)hipFree(q);
     free_stream(&p->a);
@@ -885,8 +926,30 @@ int build_binned_plan(const int *d_row_ptr, const int *d_col_ind, const double *
         return rc;
     if (int rc = own(&P.b_desc, (size_t)P.nrb * 2 + 2, &P.plan_bytes))
         return rc;
-    hipLaunchKernelGGL(bin_block_desc, dim3(blocks_for(P.nrb)), dim3(256), 0, st, P.b.ptr, P.b.shift_ptr, P.blk_fr, P.fr_ptr, P.nrb, P.b_desc);
+    hipLaunchKernelGGL(bin_block_desc, dim3(blocks_for(P.nrb)), dim3(256), 0, st, P.b.ptr, P.b.shift_ptr, P.blk_fr, P.fr_ptr, P.fr_row, P.nrb, P.b_desc);
     HIP_TRY(hipGetLastError());
+    // the packed far-row list (4 instead of 8 bytes per far row for pass B to read); the 32-bit lists go unless a block's rows span too far
+    if (getenv("SMVP_BINNED_FR32") == nullptr) {  // (development switch, plan time: set = pass B reads the 32-bit lists)
+        int *bad, h_bad = 0;
+        HIP_TRY(sc.get(&bad, 1));
+        HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), st));
+        if (int rc = own(&P.fr32, (size_t)nfr + (size_t)P.nrb + 2, &P.plan_bytes))
+            return rc;
+        hipLaunchKernelGGL(bin_far_rows_packed, dim3(blocks_for(nfr)), dim3(256), 0, st, P.fr_row, P.fr_ptr, P.blk_fr, nfr, P.nrb, P.fr32, bad);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h_bad) {
+            (void)hipFree(P.fr32);
+            P.fr32 = nullptr;
+            P.plan_bytes -= ((size_t)nfr + (size_t)P.nrb + 2) * sizeof(unsigned);
+        } else {
+            (void)hipFree(P.fr_row);
+            (void)hipFree(P.fr_ptr);
+            P.fr_row = nullptr, P.fr_ptr = nullptr;
+            P.plan_bytes -= ((size_t)nfr + 1) * sizeof(int) + ((size_t)nfr + 2) * sizeof(int);
+        }
+    }
     HIP_TRY(hipStreamSynchronize(st));
     return window();
 }
@@ -944,7 +1007,7 @@ hipError_t launch_binned_sums(const BinnedPlan &p, double *y, hipStream_t stream
 #define SMVP_BINNED_B(S, T, GG)                                                                                                  \
     if (p.slots == S && p.threads_b == T) {                                                                                    \
         hipLaunchKernelGGL((csr_binned_far_sums<S, T, GG>), dim3(grid_b), dim3(T), lds_b_bytes(S), stream, p.bins, p.b.word, p.b.chunk, \
-                           p.b_desc, p.b.shift, p.fr_row, p.fr_ptr, y, p.nrb, p.q);                                              \
+                           p.b_desc, p.b.shift, p.fr_row, p.fr_ptr, p.fr32, y, p.nrb, p.q);                                              \
         return hipGetLastError();                                                                                              \
     }
     SMVP_BINNED_B(8192, 1024, 2)

@@ -154,7 +154,9 @@ struct BinnedPlan {
     BinnedStream a, b;
     double *bins = nullptr;    // nf products, ordered (super block, column block, row, column)
     int *fr_row = nullptr, *fr_ptr = nullptr, *blk_fr = nullptr;  // far rows: row, first far entry (nfr + 1); first far row of each row block (nrb + 1)
-    int4 *b_desc = nullptr;    // pass B: two int4 per row block {a, z, k0, k1} {f0, sp, nruns, 0} (one scalar load instead of a chain)
+    int4 *b_desc = nullptr;    // pass B: two int4 per row block {a, z, k0, k1} {f0, sp, nruns, first far row} (one scalar load instead of a chain)
+    unsigned *fr32 = nullptr;  // the far rows as pass B reads them: row - the block's first | first slot << 16, a sentinel per block (nfr + nrb);
+                               // fr_row / fr_ptr are released then (kept only where a block's rows span 65536 or more)
     size_t plan_bytes = 0;
 };
 void free_binned_plan(BinnedPlan *p);
