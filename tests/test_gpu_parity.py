@@ -1721,19 +1721,42 @@ def test_sharded_eight_virtual_ranks_config5_pwt(torch):
         T_.close()
 
 
-def test_cli_virtual_gpus(torch, tmp_path):
-    """--gpus 4 --virtual-gpus on the one-GPU box: the reports equal the committed ones."""
+@pytest.mark.parametrize("exchange", [None, "copies", "direct"])
+def test_cli_virtual_gpus(torch, tmp_path, exchange):
+    """--gpus 4 --virtual-gpus [--exchange copies|direct] on the one-GPU box: the reports equal the committed ones."""
     out = tmp_path / "virt"
     out.mkdir()
-    p = subprocess.run([sm.CLI_PATH, "-c", "-t", "-n", "20", "--gpus", "4", "--virtual-gpus", "-d", str(out), ob.fixture_path("ibm32.mtx")],
-                       capture_output=True, text=True, timeout=300)
+    cmd = [sm.CLI_PATH, "-c", "-t", "-n", "20", "--gpus", "4", "--virtual-gpus"] + (["--exchange", exchange] if exchange else [])
+    p = subprocess.run(cmd + ["-d", str(out), ob.fixture_path("ibm32.mtx")], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
-    assert "4 virtual GPUs" in p.stdout
+    assert "4 virtual GPUs" in p.stdout and ("peer copies" if exchange == "copies" else "peer pushes") in p.stdout
     for alg, stamp in (("CSR", REPORTS["ibm32.mtx"][0]), ("TJDS", REPORTS["ibm32.mtx"][1])):
         files = [f for f in os.listdir(out) if "_%s_" % alg in f]
         assert len(files) == 1
         got = ob.report_y_lines(open(os.path.join(out, files[0])).read())
         assert got == ob.report_y_lines(ob.read_report("smvp-toolbox_report_%s_%s.txt" % (alg, stamp)))
+
+
+def test_cli_exchange_and_timing_flags(torch, tmp_path):
+    """--exchange takes auto | rccl | copies | direct (one GPU: every form is available) and refuses anything else; --timing
+    device-graph asks for one launch per product; the y blocks of the reports are the committed ones every way."""
+    want = ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_%s.txt" % REPORTS["ibm32.mtx"][0]))
+    for k, flags in enumerate((["--gpus", "1", "--exchange", "rccl"], ["--exchange", "auto"], ["--timing", "device-graph"], ["--timing", "device"])):
+        out = tmp_path / ("o%d" % k)
+        out.mkdir()
+        p = subprocess.run([sm.CLI_PATH, "-c", "-n", "30"] + flags + ["-d", str(out), ob.fixture_path("ibm32.mtx")],
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        f = [x for x in os.listdir(out) if "_CSR_" in x]
+        assert len(f) == 1 and ob.report_y_lines(open(os.path.join(out, f[0])).read()) == want
+        if flags == ["--timing", "device-graph"]:
+            assert "replayed from a hipGraph" in p.stdout
+        if flags == ["--timing", "device"]:
+            assert "repeating kernel" in p.stdout
+    for bad in (["--exchange", "ring"], ["--timing", "gpu"]):
+        p = subprocess.run([sm.CLI_PATH, "-c", "-n", "3"] + bad + ["-d", str(tmp_path), ob.fixture_path("ibm32.mtx")],
+                           capture_output=True, text=True, timeout=120)
+        assert p.returncode == 1 and "[ERROR]" in p.stdout + p.stderr
 
 
 def test_sharded_issuing_thread_machinery_on_one_gpu(torch, tmp_path):
