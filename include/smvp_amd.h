@@ -166,9 +166,9 @@ enum {
     SMVP_CSR_KERNEL_STREAM = 2,      /* fixed-nnz tiles, LDS-staged segmented reduction; a row is finished by
                                         the tile it starts in (one launch).  For the tiles whose columns span less than 65536 (if
                                         most are such) the plan keeps col_ind a second time as 16-bit offsets from the tile's
-                                        smallest column and the product reads those (same sums, fewer bytes); with tiles of 1024 /
-                                        2048 entries it also keeps every row's first entry as a 16-bit offset from the first entry
-                                        of the tile the row starts in, which the per-row sums read instead of row_ptr */
+                                        smallest column and the product reads those (same sums, fewer bytes); it also keeps every
+                                        row's first entry as a 16-bit offset from the first entry of the tile the row starts in,
+                                        which the per-row sums read instead of row_ptr */
     SMVP_CSR_KERNEL_STREAM_CARRY = 3, /* same tiles; a row that crosses tiles is combined from per-tile carries
                                          by a second small launch (for matrices with extremely long rows) */
     SMVP_CSR_KERNEL_COLSWEEP = 4,     /* for columns scattered over an operand far larger than L2: strips of rows whose

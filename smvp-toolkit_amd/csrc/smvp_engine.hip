@@ -147,7 +147,7 @@ struct smvp_csr {
     // offsets from the tile's smallest column (10 instead of 12 bytes per entry; csr_stream_owner<., kFlavorCsr16, .>)
     unsigned short *d_col16 = nullptr;
     int *d_col_base = nullptr;
-    // STREAM with tiles of 1024 / 2048 entries: every row's first entry as a 16-bit offset from the first entry of the tile the row
+    // STREAM: every row's first entry as a 16-bit offset from the first entry of the tile the row
     // starts in -- what phase 2 reads instead of row_ptr (2 instead of 4 bytes per row)
     unsigned short *d_row_rel = nullptr;
     bool tile_chosen = false;     // the caller named the tile size (smvp_csr_set_kernel param): the plan keeps it
@@ -469,7 +469,7 @@ int build_stream_plan(smvp_csr *h)
     if (h->kernel == SMVP_CSR_KERNEL_STREAM) {
         if (int rc = upload(&h->d_tile_next, tile_next))
             return rc;
-        if (tile >= 1024 && h->rows > 0 && getenv("SMVP_CSR_ROWREL") == nullptr) {  // (development switch, plan time: set = keep row_ptr)
+        if (h->rows > 0 && getenv("SMVP_CSR_ROWREL") == nullptr) {  // (development switch, plan time: set = keep row_ptr)
             std::vector<unsigned short> rel((size_t)h->rows);
             for (int b = 0; b < ntiles; ++b) {
                 const long long s0 = (long long)b * tile;

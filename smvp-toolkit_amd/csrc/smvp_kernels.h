@@ -50,7 +50,7 @@ struct OwnerLaunch {
     const int *col_base = nullptr;
     const unsigned short *meta16 = nullptr, *group_run = nullptr;        // kFlavorTjdsH
     const int *run_ptr = nullptr, *run_sp = nullptr;
-    const unsigned short *row_rel = nullptr;   // 1024 / 2048-entry tiles: rows' first entries relative to their tile's (or nullptr)
+    const unsigned short *row_rel = nullptr;   // rows' first entries relative to their tile's (or nullptr: row_ptr is read)
     int rows = 0, nnz = 0, ntiles = 0;
 };
 hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hipStream_t stream);

@@ -238,7 +238,7 @@ struct OwnerExtra {
     const unsigned short *group_run;  // TjdsH: per tile and group of 32 entries, the run (inside the tile) of its first entry
     const int *run_ptr;             // TjdsH: ntiles + 1 bounds of the tiles' runs in run_sp
     const int *run_sp;              // TjdsH: start_pos of every run's diagonal (0 for a tile's run of cached entries)
-    const unsigned short *row_rel;  // tiles of 1024 / 2048 entries: every row's first entry relative to the first entry of the tile it
+    const unsigned short *row_rel;  // every row's first entry relative to the first entry of the tile it
                                     // starts in (2 B per row read by the product instead of row_ptr's 4); nullptr: row_ptr itself
     unsigned long long *stamps;     // STAMPED: per-wave {first, last} wall-clock ticks of this launch
     int stream_nt;                  // TjdsS: load the pos / slot streams non-temporally (development switch)
