@@ -332,23 +332,6 @@ __global__ __launch_bounds__(256) void mark_scattered_lines(const int *__restric
     line_flag[line] = distinct >= min_tiles ? 1 : 0;
 }
 
-// sort key of stream entry e: (tile, cached?, TJDS position) -- a tile's in-place entries first, in TJDS order, then
-// its cached ones
-__global__ __launch_bounds__(256) void window_keys(const int *__restrict__ pos, int nnz, int tile,
-                                                   const unsigned char *__restrict__ line_flag, u64 *__restrict__ key,
-                                                   unsigned *__restrict__ slot, int *__restrict__ cached_count)
-{
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= nnz)
-        return;
-    const unsigned p = (unsigned)pos[e];
-    const unsigned cached = line_flag ? line_flag[p >> 4] : 0u;
-    key[e] = ((u64)(unsigned)(e / tile) << 33) | ((u64)cached << 32) | p;
-    slot[e] = (unsigned)(e % tile);
-    if (cached)
-        atomicAdd(&cached_count[e / tile], 1);
-}
-
 __device__ __forceinline__ int diagonal_of(const int *__restrict__ start_pos, int num_diag, int p)
 {
     int lo = 0, hi = num_diag - 1;
@@ -360,6 +343,25 @@ __device__ __forceinline__ int diagonal_of(const int *__restrict__ start_pos, in
             hi = mid - 1;
     }
     return lo;
+}
+
+// sort key of stream entry e: (tile, cached?, TJDS position) -- a tile's in-place entries first, in TJDS order, then
+// its cached ones (by_column: those by their permuted column instead, which is all the product needs of them)
+__global__ __launch_bounds__(256) void window_keys(const int *__restrict__ pos, int nnz, int tile,
+                                                   const unsigned char *__restrict__ line_flag, const int *__restrict__ start_pos,
+                                                   int num_diag, int by_column, u64 *__restrict__ key,
+                                                   unsigned *__restrict__ slot, int *__restrict__ cached_count)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nnz)
+        return;
+    const unsigned p = (unsigned)pos[e];
+    const unsigned cached = line_flag ? line_flag[p >> 4] : 0u;
+    const unsigned word = cached && by_column ? p - (unsigned)start_pos[diagonal_of(start_pos, num_diag, (int)p)] : p;
+    key[e] = ((u64)(unsigned)(e / tile) << 33) | ((u64)cached << 32) | word;
+    slot[e] = (unsigned)(e % tile);
+    if (cached)
+        atomicAdd(&cached_count[e / tile], 1);
 }
 
 // in-place entry: (TJDS position, slot | diagonal << slot_bits); cached entry: (permuted column, slot) -- diagonal 0, so
@@ -417,9 +419,20 @@ __global__ __launch_bounds__(256) void overflow_entries(const int *__restrict__ 
 
 namespace {
 
-// kFlavorTjdsH, pass 1 over the sorted windows.  A RUN is a stretch of one tile's sorted entries that lie in one jagged
-// diagonal (the tile's cached entries, which come last and carry their column, form one more run): head[e] = 1 where a run
-// starts, diag[e] = the entry's diagonal (-1: cached).
+// kFlavorTjdsH, pass 1 over the sorted windows.  A RUN is a stretch of one tile's sorted entries whose 32-bit word -- the TJDS
+// position of an in-place entry, the permuted column of a cached one -- lies in one aligned block of 2^16 and, in place, in
+// one jagged diagonal: inside a run the word is the run's base + 16 bits.  head[e] = 1 where a run starts, diag[e] = the
+// entry's diagonal (-1: cached).
+constexpr int kRunSpanBits = 16;
+
+__device__ __forceinline__ void run_class(u64 key, const int *__restrict__ start_pos, int num_diag, int *diag, unsigned *block)
+{
+    const bool cached = (key >> 32) & 1u;
+    const unsigned word = (unsigned)(key & 0xffffffffu);
+    *diag = cached ? -1 : diagonal_of(start_pos, num_diag, (int)word);
+    *block = word >> kRunSpanBits;
+}
+
 __global__ __launch_bounds__(256) void diagonal_run_heads(const u64 *__restrict__ key, int nnz, int tile,
                                                           const int *__restrict__ start_pos, int num_diag,
                                                           int *__restrict__ diag, int *__restrict__ head,
@@ -428,13 +441,13 @@ __global__ __launch_bounds__(256) void diagonal_run_heads(const u64 *__restrict_
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= nnz)
         return;
-    const bool cached = (key[e] >> 32) & 1u;
-    const int d = cached ? -1 : diagonal_of(start_pos, num_diag, (int)(unsigned)(key[e] & 0xffffffffu));
+    int d, pd;
+    unsigned blk, pblk;
+    run_class(key[e], start_pos, num_diag, &d, &blk);
     int h = 1;
     if (e % tile != 0) {
-        const bool pc = (key[e - 1] >> 32) & 1u;
-        const int pd = pc ? -1 : diagonal_of(start_pos, num_diag, (int)(unsigned)(key[e - 1] & 0xffffffffu));
-        h = pd != d ? 1 : 0;
+        run_class(key[e - 1], start_pos, num_diag, &pd, &pblk);
+        h = pd != d || pblk != blk ? 1 : 0;
     }
     diag[e] = d;
     head[e] = h;
@@ -442,35 +455,37 @@ __global__ __launch_bounds__(256) void diagonal_run_heads(const u64 *__restrict_
         atomicAdd(&runs_in_tile[e / tile], 1);
 }
 
-// pass 2: position (or, cached, column) per entry as in window_streams; a 16-bit word slot | run number mod 32 << 11;
-// per run the start_pos of its diagonal (0 for the cached run: column - 0); per group of 32 entries its first entry's run
+// pass 2: per entry the low 16 bits of its word and a 16-bit word slot | run number mod 32 << 11; per run {base, sub}: an
+// entry's word is base + its 16 bits, its operand x_perm[word - sub] (in place: sub = start_pos of the run's diagonal and
+// val[word] the value; cached: the word is the column, sub = 0, the value goes into the tile's run of the cache); per group
+// of 32 entries its first entry's run
 __global__ __launch_bounds__(256) void half_streams(const u64 *__restrict__ key, const unsigned *__restrict__ slot, int nnz,
-                                                    int tile, const int *__restrict__ start_pos, int num_diag,
+                                                    int tile, const int *__restrict__ pos, const int *__restrict__ start_pos,
                                                     const int *__restrict__ diag, const int *__restrict__ head,
                                                     const int *__restrict__ run_id, const int *__restrict__ run_ptr,
                                                     const int *__restrict__ cache_ptr, const double *__restrict__ val,
-                                                    int *__restrict__ pos_sorted, unsigned short *__restrict__ meta16,
-                                                    int *__restrict__ run_sp, unsigned short *__restrict__ group_run,
+                                                    unsigned short *__restrict__ off16, unsigned short *__restrict__ meta16,
+                                                    int *__restrict__ run_tab, unsigned short *__restrict__ group_run,
                                                     double *__restrict__ val_cache)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= nnz)
         return;
     const int b = e / tile, idx = e % tile;
-    const int p = (int)(unsigned)(key[e] & 0xffffffffu);
+    const unsigned word = (unsigned)(key[e] & 0xffffffffu);
     const int d = diag[e];
     const int r = run_id[e] - 1;  // run_id = inclusive scan of head
     const int local = r - run_ptr[b];
-    if (d < 0) {  // cached: its column, and its value into the tile's run of the cache
+    if (d < 0) {  // cached: its value (val at the position the row-major stream holds for its slot) into the tile's run of the cache
         const long long tile_end = (long long)(b + 1) * tile < nnz ? (long long)(b + 1) * tile : nnz;
         const int c0 = cache_ptr[b], c1 = cache_ptr[b + 1];
-        pos_sorted[e] = p - start_pos[diagonal_of(start_pos, num_diag, p)];
-        val_cache[c0 + (e - (int)(tile_end - (c1 - c0)))] = val[p];
-    } else {
-        pos_sorted[e] = p;
+        val_cache[c0 + (e - (int)(tile_end - (c1 - c0)))] = val[pos[(long long)b * tile + slot[e]]];
     }
-    if (head[e])
-        run_sp[r] = d < 0 ? 0 : start_pos[d];
+    off16[e] = (unsigned short)(word & ((1u << kRunSpanBits) - 1u));
+    if (head[e]) {
+        run_tab[2 * (size_t)r] = (int)(word & ~((1u << kRunSpanBits) - 1u));
+        run_tab[2 * (size_t)r + 1] = d < 0 ? 0 : start_pos[d];
+    }
     if (idx % 32 == 0)
         group_run[(size_t)b * (tile / 32) + idx / 32] = (unsigned short)local;
     meta16[e] = (unsigned short)(slot[e] | ((unsigned)(local & 31) << 11));
@@ -522,7 +537,7 @@ int sort_tile_windows(const int *d_pos, int nnz, int tile, const int *d_start_po
         hipLaunchKernelGGL(mark_scattered_lines, dim3(blocks_for(nlines)), dim3(256), 0, st, where, nnz, tile, cache_min_tiles, flag);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(window_keys, dim3(blocks_for(nnz)), dim3(256), 0, st, d_pos, nnz, tile, flag, k0, s0, count);
+    hipLaunchKernelGGL(window_keys, dim3(blocks_for(nnz)), dim3(256), 0, st, d_pos, nnz, tile, flag, d_start_pos, num_diag, 0, k0, s0, count);
     HIP_TRY(hipGetLastError());
     const unsigned bits = 33u + (unsigned)bits_for(ntiles + 1);
     size_t tmp_bytes = 0;
@@ -550,16 +565,17 @@ int sort_tile_windows(const int *d_pos, int nnz, int tile, const int *d_start_po
     return SMVP_OK;
 }
 
-// kFlavorTjdsH: like sort_tile_windows, but the entry's second word is 16 bits (slot | run hint) and the start_pos of its
-// diagonal comes from the tile's run table.  Allocates *d_val_cache, *d_run_sp, *d_group_run (hipFree by the caller);
-// d_cache_ptr / d_run_ptr have ntiles + 1 entries.
+// kFlavorTjdsH: like sort_tile_windows, but an entry is two 16-bit words -- the low half of its position (cached: of its
+// column) and slot | run hint -- and the rest comes from the tile's run table ({base, sub} per run, see half_streams).
+// Allocates *d_val_cache, *d_run_tab (2 ints per run), *d_group_run (hipFree by the caller); d_cache_ptr / d_run_ptr have
+// ntiles + 1 entries.
 int build_tile_half_streams(const int *d_pos, int nnz, int tile, const int *d_start_pos, int num_diag, const double *d_val,
-                            int cache_min_tiles, int *d_pos_sorted, unsigned short *d_meta16, int *d_cache_ptr, int *d_run_ptr,
-                            double **d_val_cache, int **d_run_sp, unsigned short **d_group_run, int *cached_total,
+                            int cache_min_tiles, unsigned short *d_off16, unsigned short *d_meta16, int *d_cache_ptr, int *d_run_ptr,
+                            double **d_val_cache, int **d_run_tab, unsigned short **d_group_run, int *cached_total,
                             int *runs_total, hipStream_t st)
 {
     const int ntiles = std::max(1, (int)(((long long)nnz + tile - 1) / tile));
-    *d_val_cache = nullptr, *d_run_sp = nullptr, *d_group_run = nullptr;
+    *d_val_cache = nullptr, *d_run_tab = nullptr, *d_group_run = nullptr;
     *cached_total = *runs_total = 0;
     if (tile % 32 != 0 || tile > 2048)
         return smvp::fail(SMVP_ERR_UNSUPPORTED, "build_tile_half_streams: tile %d does not fit the 16-bit word", tile);
@@ -594,7 +610,7 @@ int build_tile_half_streams(const int *d_pos, int nnz, int tile, const int *d_st
             hipLaunchKernelGGL(mark_scattered_lines, dim3(blocks_for(nlines)), dim3(256), 0, st, where, nnz, tile, cache_min_tiles, flag);
             HIP_TRY(hipGetLastError());
         }
-        hipLaunchKernelGGL(window_keys, dim3(blocks_for(nnz)), dim3(256), 0, st, d_pos, nnz, tile, flag, k0, s0, count);
+        hipLaunchKernelGGL(window_keys, dim3(blocks_for(nnz)), dim3(256), 0, st, d_pos, nnz, tile, flag, d_start_pos, num_diag, 1, k0, s0, count);
         HIP_TRY(hipGetLastError());
         const unsigned bits = 33u + (unsigned)bits_for(ntiles + 1);
         size_t tmp_bytes = 0;
@@ -620,13 +636,13 @@ int build_tile_half_streams(const int *d_pos, int nnz, int tile, const int *d_st
     *runs_total = nruns;
     const size_t groups = (size_t)ntiles * (size_t)(tile / 32);
     if (hipMalloc((void **)d_val_cache, sizeof(double) * (size_t)std::max(total, 4)) != hipSuccess ||
-        hipMalloc((void **)d_run_sp, sizeof(int) * (size_t)std::max(nruns, 4)) != hipSuccess ||
+        hipMalloc((void **)d_run_tab, 2 * sizeof(int) * (size_t)std::max(nruns, 4)) != hipSuccess ||
         hipMalloc((void **)d_group_run, sizeof(unsigned short) * std::max<size_t>(groups, 4)) != hipSuccess)
         return smvp::fail(SMVP_ERR_ALLOC, "build_tile_half_streams: cannot allocate the run tables (%d runs, %d cached values)", nruns, total);
     HIP_TRY(hipMemsetAsync(*d_group_run, 0, sizeof(unsigned short) * std::max<size_t>(groups, 4), st));
     if (nnz > 0) {
-        hipLaunchKernelGGL(half_streams, dim3(blocks_for(nnz)), dim3(256), 0, st, k1, s1, nnz, tile, d_start_pos, num_diag, dg, head, rid,
-                           d_run_ptr, d_cache_ptr, d_val, d_pos_sorted, d_meta16, *d_run_sp, *d_group_run, *d_val_cache);
+        hipLaunchKernelGGL(half_streams, dim3(blocks_for(nnz)), dim3(256), 0, st, k1, s1, nnz, tile, d_pos, d_start_pos, dg, head, rid,
+                           d_run_ptr, d_cache_ptr, d_val, d_off16, d_meta16, *d_run_tab, *d_group_run, *d_val_cache);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(st));

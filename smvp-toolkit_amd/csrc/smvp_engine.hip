@@ -133,8 +133,8 @@ struct smvp_csr {
     int *d_cache_ptr = nullptr;
     double *d_val_cache = nullptr;
     // TjdsH: the 16-bit second word of every entry, the tiles' runs (start_pos of each run's diagonal), each group of 32's run
-    unsigned short *d_meta16 = nullptr, *d_group_run = nullptr;
-    int *d_run_ptr = nullptr, *d_run_sp = nullptr;
+    unsigned short *d_meta16 = nullptr, *d_group_run = nullptr, *d_off16 = nullptr;
+    int *d_run_ptr = nullptr, *d_run_tab = nullptr;
     int runs_total = 0;
     int kernel = SMVP_CSR_KERNEL_AUTO;  // resolved: never AUTO once a plan exists
     int lanes_per_row = 64;             // VECTOR
@@ -392,13 +392,13 @@ void free_stream_plan(smvp_csr *h)
     h->d_row_rel = nullptr;
     for (void *p : {(void *)h->d_pos_sorted, (void *)h->d_meta, (void *)h->d_ovf_ptr, (void *)h->d_ovf_val, (void *)h->d_ovf_k,
                     (void *)h->d_cache_ptr, (void *)h->d_val_cache, (void *)h->d_meta16, (void *)h->d_group_run,
-                    (void *)h->d_run_ptr, (void *)h->d_run_sp})
+                    (void *)h->d_run_ptr, (void *)h->d_run_tab, (void *)h->d_off16})
         if (p)
             (void)hipFree(p);
     h->d_pos_sorted = h->d_meta = h->d_ovf_ptr = h->d_ovf_k = h->d_cache_ptr = nullptr;
     h->d_ovf_val = nullptr;
-    h->d_run_ptr = h->d_run_sp = nullptr;
-    h->d_meta16 = h->d_group_run = nullptr;
+    h->d_run_ptr = h->d_run_tab = nullptr;
+    h->d_meta16 = h->d_group_run = h->d_off16 = nullptr;
     h->d_val_cache = nullptr;
     h->cached_total = h->runs_total = 0;
     h->d_tile_row = h->d_carry_row = h->d_tile_next = nullptr;
@@ -499,22 +499,23 @@ int build_stream_plan(smvp_csr *h)
         if (int rc = upload(&h->d_ovf_ptr, ovf_ptr))
             return rc;
         const size_t n = (size_t)std::max(h->nnz, 4), m = (size_t)std::max(total, 4);
-        if (hipMalloc((void **)&h->d_pos_sorted, n * sizeof(int)) != hipSuccess ||
-            hipMalloc((void **)&h->d_ovf_val, m * sizeof(double)) != hipSuccess ||
+        if (hipMalloc((void **)&h->d_ovf_val, m * sizeof(double)) != hipSuccess ||
             hipMalloc((void **)&h->d_ovf_k, m * sizeof(int)) != hipSuccess ||
             hipMalloc((void **)&h->d_cache_ptr, ((size_t)ntiles + 2) * sizeof(int)) != hipSuccess)
             return smvp::fail(SMVP_ERR_ALLOC, "cannot allocate the tile-ordered TJDS streams");
         if (h->flavor == smvp::kFlavorTjdsH) {
-            if (hipMalloc((void **)&h->d_meta16, n * sizeof(unsigned short)) != hipSuccess ||
+            if (hipMalloc((void **)&h->d_off16, n * sizeof(unsigned short)) != hipSuccess ||
+                hipMalloc((void **)&h->d_meta16, n * sizeof(unsigned short)) != hipSuccess ||
                 hipMalloc((void **)&h->d_run_ptr, ((size_t)ntiles + 2) * sizeof(int)) != hipSuccess)
                 return smvp::fail(SMVP_ERR_ALLOC, "cannot allocate the tile-ordered TJDS streams");
             if (int rc = smvp::build_tile_half_streams(h->d_pos, h->nnz, tile, h->d_start_pos, h->num_diag, h->d_val,
-                                                       h->cache_min_tiles, h->d_pos_sorted, h->d_meta16, h->d_cache_ptr,
-                                                       h->d_run_ptr, &h->d_val_cache, &h->d_run_sp, &h->d_group_run,
+                                                       h->cache_min_tiles, h->d_off16, h->d_meta16, h->d_cache_ptr,
+                                                       h->d_run_ptr, &h->d_val_cache, &h->d_run_tab, &h->d_group_run,
                                                        &h->cached_total, &h->runs_total, nullptr))
                 return rc;
         } else {
-            if (hipMalloc((void **)&h->d_meta, n * sizeof(int)) != hipSuccess)
+            if (hipMalloc((void **)&h->d_pos_sorted, n * sizeof(int)) != hipSuccess ||
+                hipMalloc((void **)&h->d_meta, n * sizeof(int)) != hipSuccess)
                 return smvp::fail(SMVP_ERR_ALLOC, "cannot allocate the tile-ordered TJDS streams");
             if (int rc = smvp::sort_tile_windows(h->d_pos, h->nnz, tile, h->d_start_pos, h->num_diag, smvp::kSlotBits, h->d_val,
                                                  h->cache_min_tiles, h->d_pos_sorted, h->d_meta, h->d_cache_ptr, &h->d_val_cache,
@@ -839,7 +840,7 @@ static void fill_owner_launch(const smvp_csr_t *h, const double *d_x, double *d_
         l.pos = h->d_pos_sorted, l.col_ind = h->d_meta;
         l.ovf_ptr = h->d_ovf_ptr, l.ovf_val = h->d_ovf_val, l.ovf_k = h->d_ovf_k;
         l.cache_ptr = h->d_cache_ptr, l.val_cache = h->d_val_cache;
-        l.meta16 = h->d_meta16, l.group_run = h->d_group_run, l.run_ptr = h->d_run_ptr, l.run_sp = h->d_run_sp;
+        l.off16 = h->d_off16, l.meta16 = h->d_meta16, l.group_run = h->d_group_run, l.run_ptr = h->d_run_ptr, l.run_tab = h->d_run_tab;
     }
     l.stamps = stamps;
     l.rows = h->rows, l.nnz = h->nnz, l.ntiles = h->ntiles;
@@ -1023,8 +1024,8 @@ static double csr_plan_bytes(const smvp_csr_t *h)
     if (h->d_row_rel)
         b += 2.0 * h->rows;
     if (h->flavor == smvp::kFlavorTjdsS || h->flavor == smvp::kFlavorTjdsH) {
-        b += 4.0 * n + 4.0 * (t + 1) + 12.0 * h->ovf_total + 4.0 * (t + 2) + 8.0 * h->cached_total;
-        b += h->flavor == smvp::kFlavorTjdsH ? 2.0 * n + 4.0 * (t + 2) + 4.0 * h->runs_total + 2.0 * (n / 32 + 1) : 4.0 * n;
+        b += 4.0 * (t + 1) + 12.0 * h->ovf_total + 4.0 * (t + 2) + 8.0 * h->cached_total;
+        b += h->flavor == smvp::kFlavorTjdsH ? 4.0 * n + 4.0 * (t + 2) + 8.0 * h->runs_total + 2.0 * (n / 32 + 1) : 8.0 * n;
     }
     return b;
 }

@@ -213,12 +213,15 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_tiles(
 //                  lanes read neighbouring val / x_perm entries, lane t takes entries t, t + 256, ... of the tile --
 //                  and each product goes to the LDS slot of its row-major place (`col_ind` holds slot | diagonal << 11);
 //                  the entries a tile needs from beyond its end are kept a second time in row order (ovf_*)
-//   kFlavorTjdsH   kFlavorTjdsS with 6 bytes of index per entry instead of 8: the position stays a 32-bit word (the val
-//                  gather goes out the moment it arrives, as before), the second word shrinks to 16 bits -- LDS slot | the
-//                  number, modulo 32, of the entry's RUN: a stretch of the tile's sorted entries inside one jagged diagonal.
-//                  The tile's run table holds start_pos of each run's diagonal; an entry finds its run from the run of its
-//                  group of 32 entries (`group_run`, one 16-bit word per group) and the 5-bit hint, reads start_pos there
-//                  instead of start_pos[diagonal], and the x gather follows: the same two dependent steps as before.
+//   kFlavorTjdsH   kFlavorTjdsS with 4 bytes of index per entry instead of 8: two 16-bit words.  One is the LDS slot | the
+//                  number, modulo 32, of the entry's RUN: a stretch of the tile's sorted entries inside one jagged diagonal
+//                  and one aligned block of 2^16 positions (the tile's cached entries, which need only their column, are
+//                  sorted by column and form runs by blocks of 2^16 columns).  The other is the low half of the position
+//                  (cached: of the column).  The tile's run table holds {base, sub} per run: position = base + low half,
+//                  operand index = position - sub (sub = start_pos of the run's diagonal; cached: 0).  An entry finds its
+//                  run from the run of its group of 32 entries (`group_run`, one 16-bit word per group) and the 5-bit hint;
+//                  the table sits in a wavefront's registers (a handful of runs per tile on banded matrices), so the two
+//                  gathers follow the streams after two cross-lane reads.
 // ---------------------------------------------------------------------------
 typedef int int4v __attribute__((ext_vector_type(4)));               // clang vectors: what the non-temporal builtins take
 
@@ -234,10 +237,11 @@ struct OwnerExtra {
     const double *val_cache;        // TjdsS: values of the entries whose val lines scatter over many tiles, tile by tile
     const unsigned short *col16;    // Csr16: column - col_base[tile] per entry
     const int *col_base;            // Csr16: smallest column of every tile
+    const unsigned short *off16;    // TjdsH: low 16 bits of the entry's position (cached entries: of its permuted column)
     const unsigned short *meta16;   // TjdsH: slot | run hint << kSlotBits per entry
     const unsigned short *group_run;  // TjdsH: per tile and group of 32 entries, the run (inside the tile) of its first entry
-    const int *run_ptr;             // TjdsH: ntiles + 1 bounds of the tiles' runs in run_sp
-    const int *run_sp;              // TjdsH: start_pos of every run's diagonal (0 for a tile's run of cached entries)
+    const int *run_ptr;             // TjdsH: ntiles + 1 bounds of the tiles' runs in run_tab
+    const int *run_tab;             // TjdsH: per run {base of its block of 2^16 positions, start_pos of its diagonal} (cached: {column block, 0})
     const unsigned short *row_rel;  // every row's first entry relative to the first entry of the tile it
                                     // starts in (2 B per row read by the product instead of row_ptr's 4); nullptr: row_ptr itself
     unsigned long long *stamps;     // STAMPED: per-wave {first, last} wall-clock ticks of this launch
@@ -373,16 +377,18 @@ __device__ __forceinline__ void owner_body(
     double v[VPT];
     const bool full_tile = s + TILE <= (long long)nnz;
     int grp[HALF ? VPT : 1];  // TjdsH: run (inside the tile) of the first entry of this entry's group of 32
-    // TjdsH: the tile's run table (start_pos of each run's diagonal), one entry per lane, requested with the tile's own streams:
-    // an entry then takes its run's base from its wavefront's copy by a cross-lane read instead of a second, dependent
-    // trip to memory in front of the x gather (tiles with more than 64 runs read the rest as before)
-    int run0 = 0, run_tbl = 0;
+    // TjdsH: the tile's run table ({base, sub} per run), one run per lane, requested with the tile's own streams: an entry
+    // then takes its run's words from its wavefront's copy by cross-lane reads instead of a second, dependent trip to memory
+    // in front of the gathers (tiles with more than 64 runs read the rest from memory)
+    int run0 = 0;
+    int2 run_tbl = make_int2(0, 0);
     if constexpr (HALF) {
         if (full_tile) {
             run0 = ex.run_ptr[b];
             const int nruns = ex.run_ptr[b + 1] - run0;
             const int ln = t & 63;
-            run_tbl = ln < nruns ? ex.run_sp[run0 + ln] : 0;
+            if (ln < nruns)
+                run_tbl = reinterpret_cast<const int2 *>(ex.run_tab)[run0 + ln];
         }
     }
     if constexpr (HALF) {
@@ -390,10 +396,10 @@ __device__ __forceinline__ void owner_body(
 #pragma unroll
             for (int k = 0; k < VPT; ++k) {
                 if constexpr (VPT == 1) {  // 256-entry tiles: a matrix that lives in the caches and is multiplied again and again
-                    pj[k] = a.pos[s + k * kStreamBlock + t];
+                    pj[k] = ex.off16[s + k * kStreamBlock + t];
                     c[k] = ex.meta16[s + k * kStreamBlock + t];
                 } else {
-                    pj[k] = __builtin_nontemporal_load(a.pos + s + k * kStreamBlock + t);
+                    pj[k] = __builtin_nontemporal_load(ex.off16 + s + k * kStreamBlock + t);  // low half of the position
                     c[k] = __builtin_nontemporal_load(ex.meta16 + s + k * kStreamBlock + t);  // slot | run hint << kSlotBits
                 }
                 grp[k] = ex.group_run[(size_t)b * (TILE / 32) + ((k * kStreamBlock + t) >> 5)];
@@ -509,10 +515,13 @@ __device__ __forceinline__ void owner_body(
                 slot[k] = c[k] & ((1 << kSlotBits) - 1);
                 if constexpr (HALF) {
                     const int r = grp[k] + (((c[k] >> kSlotBits) - grp[k]) & 31);
-                    int sp = __shfl(run_tbl, r & 63);
-                    if (r >= 64)
-                        sp = ex.run_sp[run0 + r];
-                    c[k] = pj[k] - sp;
+                    int base = __shfl(run_tbl.x, r & 63), sub = __shfl(run_tbl.y, r & 63);
+                    if (r >= 64) {
+                        const int2 w = reinterpret_cast<const int2 *>(ex.run_tab)[run0 + r];
+                        base = w.x, sub = w.y;
+                    }
+                    pj[k] += base;
+                    c[k] = pj[k] - sub;
                 } else {
                     c[k] = pj[k] - a.start_pos[(unsigned)c[k] >> kSlotBits];
                 }
@@ -543,13 +552,16 @@ __device__ __forceinline__ void owner_body(
             for (int k = 0; k < VPT; ++k) {
                 const int idx = k * kStreamBlock + t;
                 if (s + idx < (long long)nnz) {
-                    const int pw = a.pos[s + idx];
-                    const double vv = idx < in_place ? a.val[pw] : ex.val_cache[cache0 + (idx - in_place)];
                     if constexpr (HALF) {
                         const int m = ex.meta16[s + idx], g = ex.group_run[(size_t)b * (TILE / 32) + (idx >> 5)];
                         const int r = g + (((m >> kSlotBits) - g) & 31);
-                        prod[m & ((1 << kSlotBits) - 1)] = vv * a.x[pw - ex.run_sp[ex.run_ptr[b] + r]];
+                        const int2 w = reinterpret_cast<const int2 *>(ex.run_tab)[ex.run_ptr[b] + r];
+                        const int pw = w.x + (int)ex.off16[s + idx];
+                        const double vv = idx < in_place ? a.val[pw] : ex.val_cache[cache0 + (idx - in_place)];
+                        prod[m & ((1 << kSlotBits) - 1)] = vv * a.x[pw - w.y];
                     } else {
+                        const int pw = a.pos[s + idx];
+                        const double vv = idx < in_place ? a.val[pw] : ex.val_cache[cache0 + (idx - in_place)];
                         const int m = a.col_ind[s + idx];
                         prod[m & ((1 << kSlotBits) - 1)] = vv * a.x[pw - a.start_pos[(unsigned)m >> kSlotBits]];
                     }
@@ -1133,7 +1145,7 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
     ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_val = l.ovf_val, ex.ovf_k = l.ovf_k;
     ex.cache_ptr = l.cache_ptr, ex.val_cache = l.val_cache;
     ex.col16 = l.col16, ex.col_base = l.col_base;
-    ex.meta16 = l.meta16, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_sp = l.run_sp;
+    ex.off16 = l.off16, ex.meta16 = l.meta16, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_tab = l.run_tab;
     ex.stamps = l.stamps, ex.stream_nt = nt;
     ex.row_rel = l.row_rel;
 #define SMVP_OWNER_ST(V, F, S)                                                                                     \
@@ -1228,7 +1240,7 @@ hipError_t launch_csr_stream_owner_repeat(int vpt, int flavor, const OwnerLaunch
     ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_val = l.ovf_val, ex.ovf_k = l.ovf_k;
     ex.cache_ptr = l.cache_ptr, ex.val_cache = l.val_cache;
     ex.col16 = l.col16, ex.col_base = l.col_base;
-    ex.meta16 = l.meta16, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_sp = l.run_sp;
+    ex.off16 = l.off16, ex.meta16 = l.meta16, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_tab = l.run_tab;
     ex.stamps = nullptr, ex.stream_nt = nt;
     ex.row_rel = l.row_rel;
     RepeatCtl ctl;

@@ -719,6 +719,40 @@ def test_tjds_half_words_with_a_run_per_entry(torch):
     T.close()
 
 
+def test_tjds_half_words_across_position_blocks(torch):
+    """The 16-bit position words count from the base of an aligned block of 2^16 positions (cached entries: columns): a matrix
+    whose tiles reach over many such blocks -- 300 000 columns, uniformly scattered -- gives the same bits as the plan that
+    keeps whole 32-bit words, with and without the value cache, and agrees with the serial loop."""
+    m = n = 300_000
+    rng = np.random.default_rng(77)
+    per_row = rng.integers(1, 12, m)
+    rows = np.repeat(np.arange(m), per_row)
+    cols = rng.integers(0, n, len(rows))
+    key = np.unique(rows.astype(np.int64) * n + cols)
+    rows, cols = (key // n).astype(np.int64), (key % n).astype(np.int64)
+    coo = sm.make_coo(rows, cols, rng.uniform(-1, 1, len(rows)))
+    t = sm.tjds_from_coo(coo, m, n)
+    row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
+    x = rng.random(n)
+    ref = ob.csr_spmv(row_ptr, col_ind, val, x)
+    scale = row_scale(row_ptr, col_ind, val, x)
+    want = None
+    for index in ("sorted", "half"):
+        for tile in (2048, 256, 1024):
+            T = tjds_gather_matrix(t, index, tile)
+            T.set_x(dev(torch, x))
+            for cache in (2, 0, 1):
+                T.set_value_cache(cache)
+                dy = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+                T.spmv(dy)
+                torch.cuda.synchronize()
+                if want is None:
+                    want = dy.clone()
+                    assert_close(dy.cpu().numpy(), ref, scale)
+                assert torch.equal(dy, want), (index, tile, cache)
+            T.close()
+
+
 @pytest.mark.parametrize("name", SAMPLES)
 @pytest.mark.parametrize("mode", TJDS_MODES)
 def test_tjds_sample_matrices(torch, name, mode):
