@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "smvp-toolkit_amd", "python")); sys.path.i
 
 def matrix(seed):
     rng = np.random.default_rng(70000 + seed)
-    style = seed % 8
+    style = seed % 9
     cols = int(rng.integers(1, 9000))
     if style == 0:      # total entries exactly a multiple of a tile size
         target = int(rng.choice([256, 512, 1024, 2048, 3072, 4096, 6144])) + int(rng.integers(-2, 3))
@@ -40,13 +40,27 @@ def matrix(seed):
         lens = [int(rng.choice([31, 32, 33]))] * int(rng.integers(1, 300))
     elif style == 6:    # power law
         lens = np.minimum((rng.pareto(1.1, int(rng.integers(1, 3000))) * 2).astype(int), cols).tolist()
-    else:               # a single row
+    elif style == 7:    # a single row
         lens = [int(rng.integers(0, min(cols, 5000) + 1))]
+    else:               # wide and large: positions and permuted columns reach over many blocks of 2^16 (the TJDS plan's 16-bit words)
+        cols = int(rng.integers(70_000, 400_000))
+        lens = rng.integers(0, 9, int(rng.integers(30_000, 90_000))).tolist()
+        for _ in range(int(rng.integers(0, 3))):
+            lens[int(rng.integers(0, len(lens)))] = int(rng.integers(100, 3000))
     lens = np.minimum(np.array(lens, dtype=np.int64), cols)
     rows = len(lens)
     row_ptr = np.zeros(rows + 1, dtype=np.int32)
     np.cumsum(lens, out=row_ptr[1:])
-    col_ind = np.concatenate([np.sort(rng.choice(cols, size=int(l), replace=False)) for l in lens] + [np.zeros(0, int)]).astype(np.int32)
+    if style == 8:      # (rng.choice without replacement over 400 000 columns per row is slow: draw, sort, drop repeats)
+        parts = []
+        for l in lens:
+            c = np.unique(rng.integers(0, cols, int(l)))
+            parts.append(c)
+        lens = np.array([len(c) for c in parts], dtype=np.int64)
+        np.cumsum(lens, out=row_ptr[1:])
+        col_ind = np.concatenate(parts + [np.zeros(0, int)]).astype(np.int32)
+    else:
+        col_ind = np.concatenate([np.sort(rng.choice(cols, size=int(l), replace=False)) for l in lens] + [np.zeros(0, int)]).astype(np.int32)
     val = rng.uniform(-1, 1, int(row_ptr[-1])) * 10.0 ** rng.integers(-6, 6, int(row_ptr[-1]))
     x = rng.standard_normal(cols)
     return rows, cols, row_ptr, col_ind, val, x
