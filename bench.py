@@ -1028,6 +1028,12 @@ def flat_keys(roof, others, extra, world, dist_info):
             put("config4_c_layer_overlapped_ms_%dchunk_%s" % (ch, name), ms)
     for k in ("exchange_rccl_ms", "exchange_copies_ms", "exchange_direct_ms", "exchange_chosen", "rccl_ranks"):
         put("c_layer_" + k if k in ("exchange_chosen", "rccl_ranks") else k, cl.get(k))
+    # t1 over the C layer's best overlapped step (any chunk count, any exchange form it ran): the >= 3.5x figure for the one-process,
+    # N-GPU driver, beside config4_speedup_overlapped (one process per GPU, RCCL)
+    best = [v for k, v in roof.items() if k.startswith("config4_c_layer_overlapped_ms_") and isinstance(v, float) and v > 0]
+    if best and c4.get("t1_ms"):
+        put("config4_c_layer_step_best_ms", min(best))
+        put("config4_c_layer_speedup_best", float(c4["t1_ms"]) / min(best), 3)
     hp = others.get("headline_products_only") or {}
     put("headline_products_only_ms", hp.get("ms_per_product"), 5)
     for name, e in (others.get("sample_matrices_us_per_product") or {}).items():

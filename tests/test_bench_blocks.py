@@ -174,4 +174,5 @@ def test_flat_keys_are_scalars_and_complete():
     assert roof["frac_tjds"] == 0.5 and roof["traffic_over_alg_tjds"] == 1.44 and roof["frac_tjds_colmajor"] == 0.25
     assert roof["config4_speedup_overlapped"] == 3.6 and roof["config4_chunks_chosen"] == 2 and roof["config4_eighth_ms_1chunk"] == 0.41
     assert roof["config4_c_layer_overlapped_ms_1chunk"] == 2.3 and roof["exchange_direct_ms"] == 0.05 and roof["c_layer_rccl_ranks"] == 8
+    assert roof["config4_c_layer_step_best_ms"] == 2.3 and roof["config4_c_layer_speedup_best"] == round(2.2 / 2.3, 3)
     assert roof["memplus_csr_us"] == 3.1 and roof["config5_csr_us"] == 3.7 and roof["rccl_ranks"] == 8 and roof["n_gpus"] == 8
