@@ -1156,9 +1156,10 @@ void free_row_gather(smvp_tjds *h)
     h->d_rg_ptr = h->d_rg_pos = h->d_rg_k = nullptr;
 }
 
-// How the row-gather stream names an entry: tile-ordered streams with the position and a 16-bit slot | run-hint word per
-// entry plus the tiles' run tables (kFlavorTjdsH, 6 bytes of index per entry: the default); the same order with a 32-bit
-// slot | diagonal word (kFlavorTjdsS, 8 bytes; needs the diagonals to fit 21 bits); or 32-bit permuted columns in row
+// How the row-gather stream names an entry: tile-ordered streams with two 16-bit words per entry -- the low half of the
+// position and slot | run hint -- plus the tiles' run tables (kFlavorTjdsH, 4 bytes of index per entry: the default); the same
+// order with the 32-bit position and a 32-bit slot | diagonal word (kFlavorTjdsS, 8 bytes; needs the diagonals to fit 21 bits);
+// or 32-bit permuted columns in row
 // order (kFlavorTjdsK).  SMVP_TJDS_INDEX=half|sorted|k32 selects (development switch; the tests run all three).
 int row_gather_index(const smvp_tjds *h)
 {
