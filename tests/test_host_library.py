@@ -314,6 +314,36 @@ def test_parallel_tokeniser_equals_serial(tmp_path, monkeypatch, threads, patter
     assert np.array_equal(coo["val"], np.ones(n) if pattern else v)
 
 
+def test_parallel_tokeniser_number_spellings(tmp_path, monkeypatch):
+    """The parallel tokeniser parses plain decimal tokens itself where the result is exact by construction and asks strtol /
+    strtod for everything else: every spelling %lg accepts must give the double strtod gives (Python's float is correctly
+    rounded like glibc's strtod)."""
+    rng = np.random.default_rng(7)
+    toks = ["0", "-0", "+3", "5.", ".5", "-.25", "1e22", "1e23", "1E-22", "1e-23", "9007199254740992", "9007199254740993",
+            "0.1", "0.30000000000000004", "123456789012345678", "1.7976931348623157e308", "4.9e-324", "2.2250738585072014e-308",
+            "00012.500", "1e+05", "1e0005", "12345678901234567890", "0.000000000000000000001234", "1e400", "-1e-400",
+            "inf", "-Infinity", "0x1p3", "0x.8p1", "1.5e3", "3.0E+2", "7e-1", "100000000000000000000000", "0.0", "000"]
+    for fmt in ("%.3g", "%.6g", "%.12g", "%.15g", "%.16g", "%.17g", "%e", "%f", "%.0f"):
+        for _ in range(400):
+            toks.append(fmt % (rng.uniform(-1, 1) * 10.0 ** int(rng.integers(-30, 30))))
+    toks += [str(int(v)) for v in rng.integers(-10**9, 10**9, 300)]
+    n = len(toks)
+    r, c = rng.integers(1, 1000, n), rng.integers(1, 1000, n)
+    p = tmp_path / "spell.mtx"
+    with open(p, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        f.write("1000 1000 %d\n" % n)
+        for a, b, t in zip(r, c, toks):
+            f.write("%s%d \t+%d %s\r\n" % ("000" if a % 3 == 0 else "", a, b, t))
+    want = np.array([float.fromhex(t) if "0x" in t else float(t) for t in toks])
+    for threads in ("1", "5"):
+        monkeypatch.setenv("SMVP_MM_THREADS", threads)
+        tc, m, k, coo = sm.mm_read_coo(str(p))
+        assert np.array_equal(coo["row"], r - 1) and np.array_equal(coo["col"], c - 1)
+        got = coo["val"]
+        assert got.tobytes() == want.tobytes(), [(t, g, w) for t, g, w in zip(toks, got, want) if not (g == w or (g != g and w != w))][:5]
+
+
 def test_parallel_tokeniser_on_sample_and_fallbacks(tmp_path, monkeypatch):
     monkeypatch.setenv("SMVP_MM_THREADS", "8")
     tc, m, n, coo = sm.mm_read_coo(ob.fixture_path("memplus.mtx"))
