@@ -620,8 +620,6 @@ static int csr_create_impl(smvp_csr_t **out, int device, int rows, int cols, int
     if (src) {
         h->d_pos = src->pos, h->d_start_pos = src->start_pos;
         h->num_diag = src->num_diag;
-        if (const char *e = getenv("SMVP_TJDS_CACHE"))  // development switch: 0 = no value cache, else tiles per val line
-            h->cache_min_tiles = std::min(16, std::max(0, atoi(e)));
     }
     h->rows = rows, h->cols = cols, h->nnz = nnz;
     h->h_row_ptr.resize((size_t)rows + 1);
@@ -1752,7 +1750,7 @@ int run_timed_products(RunScratch &s, int rows, int iters, const smvp_run_opts_t
         HIP_TRY(hipMalloc((void **)&st.d_stamps, sizeof(unsigned long long) * per_product * (size_t)ring));
         HIP_TRY(hipMalloc((void **)&st.d_first_last, sizeof(unsigned long long) * 2 * (size_t)ring));
         std::vector<unsigned long long> fl((size_t)ring * 2);
-        bool use_graph = getenv("SMVP_NO_GRAPH") == nullptr;
+        bool use_graph = true;
         for (int i0 = 0; i0 < iters; i0 += ring) {
             const int n = std::min(ring, iters - i0);
             auto enqueue = [&]() -> int {

@@ -245,7 +245,6 @@ struct OwnerExtra {
     const unsigned short *row_rel;  // every row's first entry relative to the first entry of the tile it
                                     // starts in (2 B per row read by the product instead of row_ptr's 4); nullptr: row_ptr itself
     unsigned long long *stamps;     // STAMPED: per-wave {first, last} wall-clock ticks of this launch
-    int stream_nt;                  // TjdsS: load the pos / slot streams non-temporally (development switch)
 };
 
 // what the helpers below need of the kernel's arguments
@@ -409,7 +408,7 @@ __device__ __forceinline__ void owner_body(
         if (full_tile) {
 #pragma unroll
             for (int k = 0; k < VPT; ++k) {
-                if (ex.stream_nt && VPT > 1) {
+                if constexpr (VPT > 1) {  // read once: non-temporal loads leave the L2 to the val / x_perm lines neighbouring tiles share
                     pj[k] = __builtin_nontemporal_load(a.pos + s + k * kStreamBlock + t);
                     c[k] = __builtin_nontemporal_load(a.col_ind + s + k * kStreamBlock + t);
                 } else {
@@ -439,16 +438,10 @@ __device__ __forceinline__ void owner_body(
                 for (int k = 0; k < VPT; k += 4)
                     *reinterpret_cast<int4 *>(&c[k]) = *reinterpret_cast<const int4 *>(a.col_ind + j0 + k);
             }
-            if constexpr (TJDS) {
-                if (ex.stream_nt) {
+            if constexpr (TJDS) {  // (read once: non-temporal)
 #pragma unroll
-                    for (int k = 0; k < VPT; k += 4)
-                        *reinterpret_cast<int4v *>(&pj[k]) = __builtin_nontemporal_load(reinterpret_cast<const int4v *>(a.pos + j0 + k));
-                } else {
-#pragma unroll
-                    for (int k = 0; k < VPT; k += 4)
-                        *reinterpret_cast<int4 *>(&pj[k]) = *reinterpret_cast<const int4 *>(a.pos + j0 + k);
-                }
+                for (int k = 0; k < VPT; k += 4)
+                    *reinterpret_cast<int4v *>(&pj[k]) = __builtin_nontemporal_load(reinterpret_cast<const int4v *>(a.pos + j0 + k));
             }
             if constexpr (CSR) {
 #pragma unroll
@@ -1135,18 +1128,12 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
         return hipSuccess;
     const int group = tile_group(l.ntiles, flavor_group(flavor));
     const dim3 grid(owner_grid(l.ntiles, group));
-    // the tile-ordered TJDS streams are read once: non-temporal loads leave the L2 to the val / x_perm lines that
-    // neighbouring tiles share (memplus x944, 2048-entry tiles: 0.538 vs 0.558 ms).  SMVP_TJDS_NT=0 turns it off.
-    static const int nt = [] {
-        const char *e = getenv("SMVP_TJDS_NT");  // development switch
-        return e ? atoi(e) : 1;
-    }();
     OwnerExtra ex;
     ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_val = l.ovf_val, ex.ovf_k = l.ovf_k;
     ex.cache_ptr = l.cache_ptr, ex.val_cache = l.val_cache;
     ex.col16 = l.col16, ex.col_base = l.col_base;
     ex.off16 = l.off16, ex.meta16 = l.meta16, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_tab = l.run_tab;
-    ex.stamps = l.stamps, ex.stream_nt = nt;
+    ex.stamps = l.stamps;
     ex.row_rel = l.row_rel;
 #define SMVP_OWNER_ST(V, F, S)                                                                                     \
     hipLaunchKernelGGL((csr_stream_owner<V, F, S>), grid, dim3(kStreamBlock), 0, stream, l.row_ptr, l.col_ind, l.val, \
@@ -1232,16 +1219,12 @@ hipError_t launch_csr_stream_owner_repeat(int vpt, int flavor, const OwnerLaunch
     if (e != hipSuccess)
         return e;
     const int group = tile_group(l.ntiles, flavor_group(flavor));
-    static const int nt = [] {
-        const char *env = getenv("SMVP_TJDS_NT");  // development switch (see launch_csr_stream_owner)
-        return env ? atoi(env) : 1;
-    }();
     OwnerExtra ex;
     ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_val = l.ovf_val, ex.ovf_k = l.ovf_k;
     ex.cache_ptr = l.cache_ptr, ex.val_cache = l.val_cache;
     ex.col16 = l.col16, ex.col_base = l.col_base;
     ex.off16 = l.off16, ex.meta16 = l.meta16, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_tab = l.run_tab;
-    ex.stamps = nullptr, ex.stream_nt = nt;
+    ex.stamps = nullptr;
     ex.row_rel = l.row_rel;
     RepeatCtl ctl;
     ctl.shard = ctl_words, ctl.go = ctl_words + 32 * kRepeatMaxShards, ctl.top = ctl_words + kRepeatCtlWords - 32;
