@@ -365,9 +365,7 @@ __global__ __launch_bounds__(THREADS) void csr_binned_far_sums(
         double acc = 0.0;
         for (int i = long_a[qi] + lane; i < long_z[qi]; i += 64)
             acc += fp[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-            acc += __shfl_down(acc, off, 64);
+        acc = wave_sum_dpp(acc);
         if (lane == 0)
             y[long_row[qi]] = long_y[qi] + acc;
     }

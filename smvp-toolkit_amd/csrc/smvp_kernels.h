@@ -174,4 +174,32 @@ hipError_t launch_binned_sums(const BinnedPlan &p, double *y, hipStream_t stream
 // share (0 ... 1) of a CSR matrix's entries with |column - row| > band: what AUTO's choice of the binned plan rests on
 int csr_far_share(const int *d_row_ptr, const int *d_col_ind, int rows, int nnz, int band, long long row0, double *share, hipStream_t stream);
 
+// A wavefront's sum without a trip through the LDS crossbar: four data-parallel-primitive steps inside each row of 16 lanes
+// (lane i += lane i + 8, + 4, + 2, + 1; lanes beyond the row read 0), then the four row sums -- lanes 0, 16, 32, 48 -- are read
+// as scalars and added in a fixed order.  Every lane returns the total.  (__shfl_down on doubles is two ds_bpermute_b32 and a
+// wait per step: the long rows of memplus x944 cost the tile kernel 5 % of its time that way.)
+template <int N>
+__device__ __forceinline__ double dpp_row_shl(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x100 + N, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x100 + N, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum_dpp(double v)
+{
+    v += dpp_row_shl<8>(v);
+    v += dpp_row_shl<4>(v);
+    v += dpp_row_shl<2>(v);
+    v += dpp_row_shl<1>(v);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        r[k] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * k), __builtin_amdgcn_readlane(lo, 16 * k));
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
+
 }  // namespace smvp

@@ -684,7 +684,7 @@ __device__ __forceinline__ void owner_body(
         double acc = 0.0;
         for (int i = long_a[q] + lane; i < zq; i += 64)
             acc += prod[i];
-        acc = shfl_down_sum<64>(acc);
+        acc = wave_sum_dpp(acc);
         if (lane == 0)
             y[long_rows[q]] = acc;
     }

@@ -61,14 +61,6 @@ static_assert(kLds <= 160 * 1024, "LDS of one CU");
 
 typedef double double2v __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ double wave_sum_fixed(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v += __shfl_down(v, o);
-    return v;
-}
-
 __global__ __launch_bounds__(kThreads) void csr_near_window(const double *__restrict__ x, double *__restrict__ y, int rows, int cols,
                                                            long long row0, int nblocks, const int *__restrict__ wave_ptr, const int *__restrict__ wave_n1,
                                                            const int *__restrict__ wave_n2, const unsigned short *__restrict__ perm16,
@@ -149,7 +141,7 @@ __global__ __launch_bounds__(kThreads) void csr_near_window(const double *__rest
                                 accs[k] = acc;
                         ++ks;
                     } else {
-                        const double s = wave_sum_fixed(acc);
+                        const double s = wave_sum_dpp(acc);
                         if (lane == 0)
                             lsum[wave + kWaves * kl] = s;
                         ++kl;
@@ -199,7 +191,7 @@ __global__ __launch_bounds__(256) void csr_near_outside_rows(int n_out, const in
     double acc = 0.0;
     for (int j = out_ptr[q] + lane; j < out_ptr[q + 1]; j += 64)
         acc += out_val[j] * x[out_col[j]];
-    acc = wave_sum_fixed(acc);
+    acc = wave_sum_dpp(acc);
     if (lane == 0)
         y[out_row[q]] = acc;
 }
