@@ -401,7 +401,11 @@ __device__ __forceinline__ void owner_body(
                     pj[k] = __builtin_nontemporal_load(ex.off16 + s + k * kStreamBlock + t);  // low half of the position
                     c[k] = __builtin_nontemporal_load(ex.meta16 + s + k * kStreamBlock + t);  // slot | run hint << kSlotBits
                 }
-                grp[k] = ex.group_run[(size_t)b * (TILE / 32) + ((k * kStreamBlock + t) >> 5)];
+                // the two group words of this wavefront's 64 entries are one aligned 32-bit word at a wave-uniform address: a
+                // scalar load instead of a vector one per lane
+                const unsigned gw = reinterpret_cast<const unsigned *>(ex.group_run)[((size_t)b * (TILE / 32) + k * (kStreamBlock / 32) +
+                                                                                     2 * __builtin_amdgcn_readfirstlane(t >> 6)) >> 1];
+                grp[k] = (t & 32) ? (int)(gw >> 16) : (int)(gw & 0xffffu);
             }
         }
     } else if constexpr (SORTED) {
