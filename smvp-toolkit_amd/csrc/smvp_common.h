@@ -24,7 +24,7 @@ int sort_tile_windows(const int *d_pos, int nnz, int tile, const int *d_start_po
                       const double *d_val, int cache_min_tiles, int *d_pos_sorted, int *d_meta, int *d_cache_ptr,
                       double **d_val_cache, int *cached_total, ihipStream_t *stream);
 int build_tile_half_streams(const int *d_pos, int nnz, int tile, const int *d_start_pos, int num_diag, const double *d_val,
-                            int cache_min_tiles, unsigned short *d_off16, unsigned short *d_meta16, int *d_cache_ptr, int *d_run_ptr,
+                            int cache_min_tiles, unsigned *d_word32, int *d_cache_ptr, int *d_run_ptr,
                             double **d_val_cache, int **d_run_tab, unsigned short **d_group_run, int *cached_total,
                             int *runs_total, ihipStream_t *stream);
 int build_column_offsets(const int *d_col_ind, int nnz, int tile, int *d_col_base, unsigned short *d_col16, int *fits,

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void diagonal_run_heads(const u64 *__restrict_
         atomicAdd(&runs_in_tile[e / tile], 1);
 }
 
-// pass 2: per entry the low 16 bits of its word and a 16-bit word slot | run number mod 32 << 11; per run {base, sub}: an
+// pass 2: per entry ONE 32-bit word: the low 16 bits of its position (column) | (slot | run number mod 32 << 11) << 16; per run {base, sub}: an
 // entry's word is base + its 16 bits, its operand x_perm[word - sub] (in place: sub = start_pos of the run's diagonal and
 // val[word] the value; cached: the word is the column, sub = 0, the value goes into the tile's run of the cache); per group
 // of 32 entries its first entry's run
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void half_streams(const u64 *__restrict__ key,
                                                     const int *__restrict__ diag, const int *__restrict__ head,
                                                     const int *__restrict__ run_id, const int *__restrict__ run_ptr,
                                                     const int *__restrict__ cache_ptr, const double *__restrict__ val,
-                                                    unsigned short *__restrict__ off16, unsigned short *__restrict__ meta16,
+                                                    unsigned *__restrict__ word32,
                                                     int *__restrict__ run_tab, unsigned short *__restrict__ group_run,
                                                     double *__restrict__ val_cache)
 {
@@ -481,14 +481,13 @@ __global__ __launch_bounds__(256) void half_streams(const u64 *__restrict__ key,
         const int c0 = cache_ptr[b], c1 = cache_ptr[b + 1];
         val_cache[c0 + (e - (int)(tile_end - (c1 - c0)))] = val[pos[(long long)b * tile + slot[e]]];
     }
-    off16[e] = (unsigned short)(word & ((1u << kRunSpanBits) - 1u));
     if (head[e]) {
         run_tab[2 * (size_t)r] = (int)(word & ~((1u << kRunSpanBits) - 1u));
         run_tab[2 * (size_t)r + 1] = d < 0 ? 0 : start_pos[d];
     }
     if (idx % 32 == 0)
         group_run[(size_t)b * (tile / 32) + idx / 32] = (unsigned short)local;
-    meta16[e] = (unsigned short)(slot[e] | ((unsigned)(local & 31) << 11));
+    word32[e] = (word & ((1u << kRunSpanBits) - 1u)) | ((slot[e] | ((unsigned)(local & 31) << 11)) << 16);
 }
 
 }  // namespace
@@ -570,7 +569,7 @@ int sort_tile_windows(const int *d_pos, int nnz, int tile, const int *d_start_po
 // Allocates *d_val_cache, *d_run_tab (2 ints per run), *d_group_run (hipFree by the caller); d_cache_ptr / d_run_ptr have
 // ntiles + 1 entries.
 int build_tile_half_streams(const int *d_pos, int nnz, int tile, const int *d_start_pos, int num_diag, const double *d_val,
-                            int cache_min_tiles, unsigned short *d_off16, unsigned short *d_meta16, int *d_cache_ptr, int *d_run_ptr,
+                            int cache_min_tiles, unsigned *d_word32, int *d_cache_ptr, int *d_run_ptr,
                             double **d_val_cache, int **d_run_tab, unsigned short **d_group_run, int *cached_total,
                             int *runs_total, hipStream_t st)
 {
@@ -642,7 +641,7 @@ int build_tile_half_streams(const int *d_pos, int nnz, int tile, const int *d_st
     HIP_TRY(hipMemsetAsync(*d_group_run, 0, sizeof(unsigned short) * std::max<size_t>(groups, 4), st));
     if (nnz > 0) {
         hipLaunchKernelGGL(half_streams, dim3(blocks_for(nnz)), dim3(256), 0, st, k1, s1, nnz, tile, d_pos, d_start_pos, dg, head, rid,
-                           d_run_ptr, d_cache_ptr, d_val, d_off16, d_meta16, *d_run_tab, *d_group_run, *d_val_cache);
+                           d_run_ptr, d_cache_ptr, d_val, d_word32, *d_run_tab, *d_group_run, *d_val_cache);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(st));

@@ -133,7 +133,8 @@ struct smvp_csr {
     int *d_cache_ptr = nullptr;
     double *d_val_cache = nullptr;
     // TjdsH: the 16-bit second word of every entry, the tiles' runs (start_pos of each run's diagonal), each group of 32's run
-    unsigned short *d_meta16 = nullptr, *d_group_run = nullptr, *d_off16 = nullptr;
+    unsigned short *d_group_run = nullptr;
+    unsigned *d_word32 = nullptr;
     int *d_run_ptr = nullptr, *d_run_tab = nullptr;
     int runs_total = 0;
     int kernel = SMVP_CSR_KERNEL_AUTO;  // resolved: never AUTO once a plan exists
@@ -391,14 +392,15 @@ void free_stream_plan(smvp_csr *h)
     h->d_col_base = nullptr;
     h->d_row_rel = nullptr;
     for (void *p : {(void *)h->d_pos_sorted, (void *)h->d_meta, (void *)h->d_ovf_ptr, (void *)h->d_ovf_val, (void *)h->d_ovf_k,
-                    (void *)h->d_cache_ptr, (void *)h->d_val_cache, (void *)h->d_meta16, (void *)h->d_group_run,
-                    (void *)h->d_run_ptr, (void *)h->d_run_tab, (void *)h->d_off16})
+                    (void *)h->d_cache_ptr, (void *)h->d_val_cache, (void *)h->d_word32, (void *)h->d_group_run,
+                    (void *)h->d_run_ptr, (void *)h->d_run_tab})
         if (p)
             (void)hipFree(p);
     h->d_pos_sorted = h->d_meta = h->d_ovf_ptr = h->d_ovf_k = h->d_cache_ptr = nullptr;
     h->d_ovf_val = nullptr;
     h->d_run_ptr = h->d_run_tab = nullptr;
-    h->d_meta16 = h->d_group_run = h->d_off16 = nullptr;
+    h->d_group_run = nullptr;
+    h->d_word32 = nullptr;
     h->d_val_cache = nullptr;
     h->cached_total = h->runs_total = 0;
     h->d_tile_row = h->d_carry_row = h->d_tile_next = nullptr;
@@ -504,12 +506,11 @@ int build_stream_plan(smvp_csr *h)
             hipMalloc((void **)&h->d_cache_ptr, ((size_t)ntiles + 2) * sizeof(int)) != hipSuccess)
             return smvp::fail(SMVP_ERR_ALLOC, "cannot allocate the tile-ordered TJDS streams");
         if (h->flavor == smvp::kFlavorTjdsH) {
-            if (hipMalloc((void **)&h->d_off16, n * sizeof(unsigned short)) != hipSuccess ||
-                hipMalloc((void **)&h->d_meta16, n * sizeof(unsigned short)) != hipSuccess ||
+            if (hipMalloc((void **)&h->d_word32, n * sizeof(unsigned)) != hipSuccess ||
                 hipMalloc((void **)&h->d_run_ptr, ((size_t)ntiles + 2) * sizeof(int)) != hipSuccess)
                 return smvp::fail(SMVP_ERR_ALLOC, "cannot allocate the tile-ordered TJDS streams");
             if (int rc = smvp::build_tile_half_streams(h->d_pos, h->nnz, tile, h->d_start_pos, h->num_diag, h->d_val,
-                                                       h->cache_min_tiles, h->d_off16, h->d_meta16, h->d_cache_ptr,
+                                                       h->cache_min_tiles, h->d_word32, h->d_cache_ptr,
                                                        h->d_run_ptr, &h->d_val_cache, &h->d_run_tab, &h->d_group_run,
                                                        &h->cached_total, &h->runs_total, nullptr))
                 return rc;
@@ -838,7 +839,7 @@ static void fill_owner_launch(const smvp_csr_t *h, const double *d_x, double *d_
         l.pos = h->d_pos_sorted, l.col_ind = h->d_meta;
         l.ovf_ptr = h->d_ovf_ptr, l.ovf_val = h->d_ovf_val, l.ovf_k = h->d_ovf_k;
         l.cache_ptr = h->d_cache_ptr, l.val_cache = h->d_val_cache;
-        l.off16 = h->d_off16, l.meta16 = h->d_meta16, l.group_run = h->d_group_run, l.run_ptr = h->d_run_ptr, l.run_tab = h->d_run_tab;
+        l.word32 = h->d_word32, l.group_run = h->d_group_run, l.run_ptr = h->d_run_ptr, l.run_tab = h->d_run_tab;
     }
     l.stamps = stamps;
     l.rows = h->rows, l.nnz = h->nnz, l.ntiles = h->ntiles;

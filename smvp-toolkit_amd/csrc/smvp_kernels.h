@@ -48,7 +48,8 @@ struct OwnerLaunch {
     const double *val_cache = nullptr;
     const unsigned short *col16 = nullptr;                               // kFlavorCsr16
     const int *col_base = nullptr;
-    const unsigned short *off16 = nullptr, *meta16 = nullptr, *group_run = nullptr;        // kFlavorTjdsH
+    const unsigned short *group_run = nullptr;        // kFlavorTjdsH
+    const unsigned *word32 = nullptr;
     const int *run_ptr = nullptr, *run_tab = nullptr;
     const unsigned short *row_rel = nullptr;   // rows' first entries relative to their tile's (or nullptr: row_ptr is read)
     int rows = 0, nnz = 0, ntiles = 0;

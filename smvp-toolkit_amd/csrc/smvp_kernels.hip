@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_tiles(
 //                  lanes read neighbouring val / x_perm entries, lane t takes entries t, t + 256, ... of the tile --
 //                  and each product goes to the LDS slot of its row-major place (`col_ind` holds slot | diagonal << 11);
 //                  the entries a tile needs from beyond its end are kept a second time in row order (ovf_*)
-//   kFlavorTjdsH   kFlavorTjdsS with 4 bytes of index per entry instead of 8: two 16-bit words.  One is the LDS slot | the
+//   kFlavorTjdsH   kFlavorTjdsS with 4 bytes of index per entry instead of 8: two 16-bit halves of one word.  One is the LDS slot | the
 //                  number, modulo 32, of the entry's RUN: a stretch of the tile's sorted entries inside one jagged diagonal
 //                  and one aligned block of 2^16 positions (the tile's cached entries, which need only their column, are
 //                  sorted by column and form runs by blocks of 2^16 columns).  The other is the low half of the position
@@ -237,8 +237,7 @@ struct OwnerExtra {
     const double *val_cache;        // TjdsS: values of the entries whose val lines scatter over many tiles, tile by tile
     const unsigned short *col16;    // Csr16: column - col_base[tile] per entry
     const int *col_base;            // Csr16: smallest column of every tile
-    const unsigned short *off16;    // TjdsH: low 16 bits of the entry's position (cached entries: of its permuted column)
-    const unsigned short *meta16;   // TjdsH: slot | run hint << kSlotBits per entry
+    const unsigned *word32;         // TjdsH, per entry: low 16 bits of its position (cached entries: of its permuted column) | (slot | run hint << kSlotBits) << 16
     const unsigned short *group_run;  // TjdsH: per tile and group of 32 entries, the run (inside the tile) of its first entry
     const int *run_ptr;             // TjdsH: ntiles + 1 bounds of the tiles' runs in run_tab
     const int *run_tab;             // TjdsH: per run {base of its block of 2^16 positions, start_pos of its diagonal} (cached: {column block, 0})
@@ -395,11 +394,9 @@ __device__ __forceinline__ void owner_body(
 #pragma unroll
             for (int k = 0; k < VPT; ++k) {
                 if constexpr (VPT == 1) {  // 256-entry tiles: a matrix that lives in the caches and is multiplied again and again
-                    pj[k] = ex.off16[s + k * kStreamBlock + t];
-                    c[k] = ex.meta16[s + k * kStreamBlock + t];
+                    pj[k] = (int)ex.word32[s + k * kStreamBlock + t];
                 } else {
-                    pj[k] = __builtin_nontemporal_load(ex.off16 + s + k * kStreamBlock + t);  // low half of the position
-                    c[k] = __builtin_nontemporal_load(ex.meta16 + s + k * kStreamBlock + t);  // slot | run hint << kSlotBits
+                    pj[k] = (int)__builtin_nontemporal_load(ex.word32 + s + k * kStreamBlock + t);  // low half of the position | (slot | run hint) << 16
                 }
                 // the two group words of this wavefront's 64 entries are one aligned 32-bit word at a wave-uniform address: a
                 // scalar load instead of a vector one per lane
@@ -509,6 +506,8 @@ __device__ __forceinline__ void owner_body(
             int slot[VPT];
 #pragma unroll
             for (int k = 0; k < VPT; ++k) {
+                if constexpr (HALF)
+                    c[k] = (int)((unsigned)pj[k] >> 16), pj[k] &= 0xffff;  // the entry's word: low half of the position | (slot | run hint) << 16
                 slot[k] = c[k] & ((1 << kSlotBits) - 1);
                 if constexpr (HALF) {
                     const int r = grp[k] + (((c[k] >> kSlotBits) - grp[k]) & 31);
@@ -550,10 +549,11 @@ __device__ __forceinline__ void owner_body(
                 const int idx = k * kStreamBlock + t;
                 if (s + idx < (long long)nnz) {
                     if constexpr (HALF) {
-                        const int m = ex.meta16[s + idx], g = ex.group_run[(size_t)b * (TILE / 32) + (idx >> 5)];
+                        const unsigned w32 = ex.word32[s + idx];
+                        const int m = (int)(w32 >> 16), g = ex.group_run[(size_t)b * (TILE / 32) + (idx >> 5)];
                         const int r = g + (((m >> kSlotBits) - g) & 31);
                         const int2 w = reinterpret_cast<const int2 *>(ex.run_tab)[ex.run_ptr[b] + r];
-                        const int pw = w.x + (int)ex.off16[s + idx];
+                        const int pw = w.x + (int)(w32 & 0xffffu);
                         const double vv = idx < in_place ? a.val[pw] : ex.val_cache[cache0 + (idx - in_place)];
                         prod[m & ((1 << kSlotBits) - 1)] = vv * a.x[pw - w.y];
                     } else {
@@ -1136,7 +1136,7 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
     ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_val = l.ovf_val, ex.ovf_k = l.ovf_k;
     ex.cache_ptr = l.cache_ptr, ex.val_cache = l.val_cache;
     ex.col16 = l.col16, ex.col_base = l.col_base;
-    ex.off16 = l.off16, ex.meta16 = l.meta16, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_tab = l.run_tab;
+    ex.word32 = l.word32, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_tab = l.run_tab;
     ex.stamps = l.stamps;
     ex.row_rel = l.row_rel;
 #define SMVP_OWNER_ST(V, F, S)                                                                                     \
@@ -1227,7 +1227,7 @@ hipError_t launch_csr_stream_owner_repeat(int vpt, int flavor, const OwnerLaunch
     ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_val = l.ovf_val, ex.ovf_k = l.ovf_k;
     ex.cache_ptr = l.cache_ptr, ex.val_cache = l.val_cache;
     ex.col16 = l.col16, ex.col_base = l.col_base;
-    ex.off16 = l.off16, ex.meta16 = l.meta16, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_tab = l.run_tab;
+    ex.word32 = l.word32, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_tab = l.run_tab;
     ex.stamps = nullptr;
     ex.row_rel = l.row_rel;
     RepeatCtl ctl;
