@@ -2189,3 +2189,43 @@ def test_gpu_y_against_committed_golden_vectors(torch, name):
     assert_close(y, g["y_csr"], row_scale(row_ptr, col_ind, val, np.ones(n)), exact=name in EXACT)
     yq, _, _ = sm.tjds_compute(coo, m, n, iters=1, ref_quirks=True)
     assert_close(yq, g["y_tjds_refquirks"], row_scale(row_ptr, col_ind, val, np.ones(n)), exact=name in EXACT)
+
+
+def test_products_can_be_captured_in_a_callers_graph(torch):
+    """A caller may record the products into a hipGraph of its own (one warm call first: plans and function attributes are set
+    up outside the capture): the tile kernel, the column sweep, the binned plan's three kernels on their two streams, the vector
+    kernel and the TJDS product (operand permutation + product) replay with new operands and give the oracle's result."""
+    M = 1 << 16
+    rp, ci, v = sm.synth_csr(sm.SYNTH_MEMPLUS_SHAPED, 12345, M, M)
+    rng = np.random.default_rng(3)
+    xs = [rng.random(M) for _ in range(3)]
+    A = sm.CsrMatrix(M, M, rp, ci, v)
+    coo = sm.make_coo(np.repeat(np.arange(M), np.diff(rp)), ci, v)
+    T = sm.TjdsMatrix(sm.tjds_from_coo(coo, M, M))
+    dx = torch.zeros(M, dtype=torch.float64, device="cuda")
+    dy = torch.zeros(M, dtype=torch.float64, device="cuda")
+    forms = [("stream", lambda: A.set_kernel(sm.CSR_KERNEL_STREAM, 0), lambda st: A.spmv(dx, dy, stream=st)),
+             ("colsweep", lambda: A.set_kernel(sm.CSR_KERNEL_COLSWEEP, 0), lambda st: A.spmv(dx, dy, stream=st)),
+             ("binned", lambda: A.set_kernel(sm.CSR_KERNEL_BINNED, 0), lambda st: A.spmv(dx, dy, stream=st)),
+             ("vector", lambda: A.set_kernel(sm.CSR_KERNEL_VECTOR, 8), lambda st: A.spmv(dx, dy, stream=st)),
+             ("tjds", lambda: None, lambda st: (T.set_x(dx, stream=st), T.spmv(dy, stream=st)))]
+    for name, setup, run in forms:
+        setup()
+        dx.copy_(torch.from_numpy(xs[0]))
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            run(s)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                run(s)
+        for x in xs:
+            dx.copy_(torch.from_numpy(x))
+            dy.fill_(float("nan"))
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            assert_close(dy.cpu().numpy(), ob.csr_spmv(rp, ci, v, x), row_scale(rp, ci, v, x))
+        del g
+    A.close()
+    T.close()
