@@ -2229,3 +2229,56 @@ def test_products_can_be_captured_in_a_callers_graph(torch):
         del g
     A.close()
     T.close()
+
+
+def test_host_threads_with_their_own_handles_and_streams(torch):
+    """The library is re-entrant per handle (SURVEY 8(b) "Threading"): six host threads create, plan, multiply with and destroy
+    their own CSR / TJDS handles on their own streams at the same time -- every kernel family, the binned plan's side stream
+    included -- and call the reference-shaped entry point concurrently; every result is the oracle's."""
+    import threading
+
+    M = 1 << 16
+    rp, ci, v = sm.synth_csr(sm.SYNTH_MEMPLUS_SHAPED, 12345, M, M)
+    tj = sm.tjds_from_coo(sm.make_coo(np.repeat(np.arange(M), np.diff(rp)), ci, v), M, M)
+    m32, n32, coo32 = load("ibm32.mtx")
+    want32 = ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_1615284655.txt"))
+    kernels = [(sm.CSR_KERNEL_STREAM, 0), (sm.CSR_KERNEL_COLSWEEP, 0), (sm.CSR_KERNEL_BINNED, 0), (sm.CSR_KERNEL_VECTOR, 8)]
+    errors = []
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(0)
+            rng = np.random.default_rng(k)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for it in range(4):
+                    A = sm.CsrMatrix(M, M, rp, ci, v)
+                    T = sm.TjdsMatrix(tj)
+                    A.set_kernel(*kernels[(k + it) % 4])
+                    x = rng.random(M)
+                    dx = torch.from_numpy(x).cuda()
+                    dy = torch.full((M,), float("nan"), dtype=torch.float64, device="cuda")
+                    dt = torch.full((M,), float("nan"), dtype=torch.float64, device="cuda")
+                    for _ in range(5):
+                        A.spmv(dx, dy, stream=s)
+                        T.set_x(dx, stream=s)
+                        T.spmv(dt, stream=s)
+                    s.synchronize()
+                    ref, scale = ob.csr_spmv(rp, ci, v, x), row_scale(rp, ci, v, x)
+                    for what, got in (("csr", dy), ("tjds", dt)):
+                        if not np.all(np.abs(got.cpu().numpy() - ref) <= 1e-9 * scale):
+                            errors.append((what, k, it))
+                    A.close()
+                    T.close()
+            y, ms, st = sm.csr_compute(coo32, m32, n32, iters=50)
+            if ob.fmt_g(y) != want32:
+                errors.append(("compute", k))
+        except Exception as e:   # a thread's exception must fail the test, not vanish
+            errors.append((k, type(e).__name__, str(e)[:200]))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert errors == []
