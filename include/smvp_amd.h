@@ -270,8 +270,9 @@ int smvp_tjds_spmv(smvp_tjds_t *h, double *d_y, void *stream);
  *   start_pos / perm are only read); every tile of 2048 entries lists its entries in TJDS order and walks its piece of
  *   the jagged diagonals the way the format stores them, the products meet in LDS and one lane (or wave) per row sums
  *   them in ascending TJDS position -- no atomics, bit-reproducible, y needs no zeroing.
- * TWO_PHASE: products stored once per entry (column-major kernel), then summed per row through a row-inverted index
- *   -- same order of summation, same bits, two launches and 12 B per entry more traffic.
+ * TWO_PHASE: products stored once per entry (column-major kernel: thread k walks down permuted column k with x_perm[k] in a
+ *   register), then summed per row by the one-kernel form's tile kernel reading the products where that reads val (no value
+ *   cache, no operand) -- same order of summation, same bits, two launches and 16 B per entry more traffic.
  * ATOMIC: one column-major pass, fp64 atomic adds into a zeroed y (order varies from run to run).  Ref-quirks mode
  *   always runs this form.
  * The plans of the first two are built on the device the first time the mode is selected. */

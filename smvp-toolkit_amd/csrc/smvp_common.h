@@ -30,5 +30,6 @@ int build_tile_half_streams(const int *d_pos, int nnz, int tile, const int *d_st
 int build_column_offsets(const int *d_col_ind, int nnz, int tile, int *d_col_base, unsigned short *d_col16, int *fits,
                          ihipStream_t *stream);
 int build_tile_overflow(const int *d_pos, const int *d_ovf_ptr, int total, int ntiles, int tile, int nnz,
-                        const int *d_start_pos, int num_diag, const double *d_val, double *d_ovf_val, int *d_ovf_k, ihipStream_t *stream);
+                        const int *d_start_pos, int num_diag, const double *d_val, double *d_ovf_val, int *d_ovf_k, int positions,
+                        ihipStream_t *stream);
 }

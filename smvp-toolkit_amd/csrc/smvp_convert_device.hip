@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void window_streams(const u64 *__restrict__ ke
 __global__ __launch_bounds__(256) void overflow_entries(const int *__restrict__ pos, const int *__restrict__ ovf_ptr,
                                                         int ntiles, int tile, int nnz, const int *__restrict__ start_pos,
                                                         int num_diag, const double *__restrict__ val, double *__restrict__ ovf_val,
-                                                        int *__restrict__ ovf_k)
+                                                        int *__restrict__ ovf_k, int positions)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= ovf_ptr[ntiles])
@@ -411,6 +411,10 @@ __global__ __launch_bounds__(256) void overflow_entries(const int *__restrict__ 
     const int p = pos[e + (i - ovf_ptr[lo])];
     // the entry's VALUE, not its position: the tile that finishes the row reads it coalesced instead of gathering val[position]
     // (2.2 M overflow entries on memplus x944, each a gather of its own: 158 MB of 2.33 GB, profiles/r05_tjds_traffic_by_stream.txt)
+    if (positions) {  // (unit operand: the values are written anew before every product -- the tile gathers val[position] itself)
+        ovf_k[i] = p;
+        return;
+    }
     ovf_val[i] = val[p];
     ovf_k[i] = p - start_pos[diagonal_of(start_pos, num_diag, p)];
 }
@@ -650,12 +654,13 @@ int build_tile_half_streams(const int *d_pos, int nnz, int tile, const int *d_st
 
 // the entries [e_b, tile_next_b) every tile b needs from beyond its end, kept in row order: ovf_ptr[ntiles + 1] (device)
 int build_tile_overflow(const int *d_pos, const int *d_ovf_ptr, int total, int ntiles, int tile, int nnz,
-                        const int *d_start_pos, int num_diag, const double *d_val, double *d_ovf_val, int *d_ovf_k, hipStream_t st)
+                        const int *d_start_pos, int num_diag, const double *d_val, double *d_ovf_val, int *d_ovf_k, int positions,
+                        hipStream_t st)
 {
     if (total <= 0)
         return SMVP_OK;
     hipLaunchKernelGGL(overflow_entries, dim3(blocks_for(total)), dim3(256), 0, st, d_pos, d_ovf_ptr, ntiles, tile, nnz,
-                       d_start_pos, num_diag, d_val, d_ovf_val, d_ovf_k);
+                       d_start_pos, num_diag, d_val, d_ovf_val, d_ovf_k, positions);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     return SMVP_OK;

@@ -130,6 +130,7 @@ struct smvp_csr {
     // hit); from four on its entries belong to unrelated rows.  Measured on memplus x944 (profiles/r03_tjds_forms_measured.txt):
     // none 0.555 ms / 3.66 GB moved, >= 8 tiles 0.461 / 2.92 (20 % of the values cached), >= 4 tiles 0.444 / 2.73 (35 %).
     int cache_min_tiles = 2, cached_total = 0, ovf_total = 0;  // 2: every val line that is not one tile's alone (measured, r04)
+    bool unit_operand = false;  // TjdsH as the second phase of the two-phase TJDS product (see TjdsSource)
     int *d_cache_ptr = nullptr;
     double *d_val_cache = nullptr;
     // TjdsH: the 16-bit second word of every entry, the tiles' runs (start_pos of each run's diagonal), each group of 32's run
@@ -524,7 +525,7 @@ int build_stream_plan(smvp_csr *h)
                 return rc;
         }
         if (int rc = smvp::build_tile_overflow(h->d_pos, h->d_ovf_ptr, total, ntiles, tile, h->nnz, h->d_start_pos,
-                                               h->num_diag, h->d_val, h->d_ovf_val, h->d_ovf_k, nullptr))
+                                               h->num_diag, h->d_val, h->d_ovf_val, h->d_ovf_k, h->unit_operand ? 1 : 0, nullptr))
             return rc;
     }
     return SMVP_OK;
@@ -590,6 +591,9 @@ struct TjdsSource {
     const int *pos = nullptr;
     const int *start_pos = nullptr;
     int num_diag = 0;
+    // the two-phase product's second phase: `val` holds the products of the first phase (written anew before every launch: no value
+    // cache, overflow entries by position), the operand is the unit vector (no x gather)
+    bool unit_operand = false;
 };
 
 static int build_binned(smvp_csr *h, int band);
@@ -600,10 +604,9 @@ static int csr_create_impl(smvp_csr_t **out, int device, int rows, int cols, int
                            int mem_kind, const int *host_row_ptr, int flavor, const TjdsSource *src = nullptr,
                            bool plain_only = false, long long first_row = 0)
 {
-    const bool unit_val = flavor == smvp::kFlavorUnit;
     const bool plain = flavor == smvp::kFlavorCsr;
     if (!out || rows < 0 || cols < 0 || nnz < 0 || !row_ptr ||
-        (nnz > 0 && ((!col_ind && flavor != smvp::kFlavorTjdsS && flavor != smvp::kFlavorTjdsH) || (!val && !unit_val))))
+        (nnz > 0 && ((!col_ind && flavor != smvp::kFlavorTjdsS && flavor != smvp::kFlavorTjdsH) || !val)))
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: bad argument");
     if (mem_kind != SMVP_MEM_HOST && mem_kind != SMVP_MEM_DEVICE)
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_create: bad mem_kind");
@@ -621,6 +624,9 @@ static int csr_create_impl(smvp_csr_t **out, int device, int rows, int cols, int
     if (src) {
         h->d_pos = src->pos, h->d_start_pos = src->start_pos;
         h->num_diag = src->num_diag;
+        h->unit_operand = src->unit_operand;
+        if (h->unit_operand)
+            h->cache_min_tiles = 0;
     }
     h->rows = rows, h->cols = cols, h->nnz = nnz;
     h->h_row_ptr.resize((size_t)rows + 1);
@@ -657,7 +663,7 @@ static int csr_create_impl(smvp_csr_t **out, int device, int rows, int cols, int
         rc = to_device(&h->d_row_ptr, row_ptr, (size_t)rows + 1, mem_kind, &h->own_row_ptr);
     if (rc == SMVP_OK && col_ind)
         rc = to_device(&h->d_col_ind, col_ind, (size_t)nnz, mem_kind, &h->own_col_ind);
-    if (rc == SMVP_OK && !unit_val)
+    if (rc == SMVP_OK)
         rc = to_device(&h->d_val, val, (size_t)nnz, mem_kind, &h->own_val);
     if (rc == SMVP_OK) {
         const double t0 = wall_ms();
@@ -845,6 +851,7 @@ static void fill_owner_launch(const smvp_csr_t *h, const double *d_x, double *d_
     l.rows = h->rows, l.nnz = h->nnz, l.ntiles = h->ntiles;
     l.col16 = h->d_col16, l.col_base = h->d_col_base;
     l.row_rel = h->d_row_rel;
+    l.unit_x = h->unit_operand ? 1 : 0;
 }
 
 // `reps` products of the tile kernel in ONE launch, each product's window stamped (csr_stream_owner_repeat); grid from
@@ -1203,8 +1210,13 @@ int ensure_two_phase(smvp_tjds *h)
         return smvp::fail(SMVP_ERR_ALLOC, "TJDS: cannot allocate the two-phase buffers");
     if (int rc = smvp::build_row_inverse(h->d_row_ind, h->nnz, h->rows, h->d_inv_ptr, h->d_inv_pos, nullptr))
         return rc;
-    return csr_create_impl(&h->inv, h->device, h->rows, std::max(h->nnz, 1), h->nnz, h->d_inv_ptr, h->d_inv_pos, nullptr,
-                           SMVP_MEM_DEVICE, nullptr, smvp::kFlavorUnit);
+    // the second phase walks the products the way the one-kernel form walks val: every tile's entries in TJDS order (neighbouring
+    // lanes read neighbouring products), one 32-bit index word per entry, no operand (round 5; before: a unit-value CSR over the
+    // row-inverted index, every product a gather of its own: 0.83 ms on memplus x944)
+    TjdsSource src;
+    src.pos = h->d_inv_pos, src.start_pos = h->d_start_pos, src.num_diag = h->num_diag, src.unit_operand = true;
+    return csr_create_impl(&h->inv, h->device, h->rows, std::max(h->cols, 1), h->nnz, h->d_inv_ptr, nullptr, h->d_prod,
+                           SMVP_MEM_DEVICE, nullptr, smvp::kFlavorTjdsH, &src);
 }
 
 int ensure_mode_plan(smvp_tjds *h)
@@ -1393,7 +1405,7 @@ extern "C" int smvp_tjds_describe(const smvp_tjds_t *h, char *kernel_name, size_
             snprintf(kernel_name, cap, "tjds_colmajor_scatter<%s>", h->quirks ? "true" : "false");
         else if (h->mode == SMVP_TJDS_MODE_TWO_PHASE)
             snprintf(kernel_name, cap, "tjds_colmajor_products + csr_stream_owner<%d, %d, false>", h->inv ? h->inv->vpt : 0,
-                     smvp::kFlavorUnit);
+                     h->inv ? h->inv->flavor : 0);
         else
             snprintf(kernel_name, cap, "csr_stream_owner<%d, %d, false>", h->rg ? h->rg->vpt : 0, h->rg ? h->rg->flavor : 0);
     }

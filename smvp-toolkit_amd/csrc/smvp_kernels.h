@@ -26,7 +26,7 @@ hipError_t launch_csr_stream(int vpt, const int *row_ptr, const int *col_ind, co
                              double *carry, int rows, int nnz, int ntiles, hipStream_t stream);
 // what an entry of the owner kernel's stream is (see csr_stream_owner)
 constexpr int kFlavorCsr = 0;    // val[j] * x[col_ind[j]]
-constexpr int kFlavorUnit = 1;   // x[col_ind[j]]
+                                 // (1 was a unit-value CSR: the two-phase TJDS product's second phase until round 5)
 constexpr int kFlavorTjdsK = 2;  // val[pos[j]] * x_perm[col_ind[j]]   (col_ind = permuted column k)
 constexpr int kFlavorTjdsS = 3;  // the same entries, every tile's in TJDS order; col_ind = LDS slot | diagonal << kSlotBits
 constexpr int kFlavorTjdsH = 4;  // kFlavorTjdsS with a 16-bit second word: slot | run hint << 11; the start_pos of the entry's
@@ -50,6 +50,7 @@ struct OwnerLaunch {
     const int *col_base = nullptr;
     const unsigned short *group_run = nullptr;        // kFlavorTjdsH
     const unsigned *word32 = nullptr;
+    int unit_x = 0;                            // kFlavorTjdsH: the operand is the unit vector (second phase of the two-phase TJDS product)
     const int *run_ptr = nullptr, *run_tab = nullptr;
     const unsigned short *row_rel = nullptr;   // rows' first entries relative to their tile's (or nullptr: row_ptr is read)
     int rows = 0, nnz = 0, ntiles = 0;

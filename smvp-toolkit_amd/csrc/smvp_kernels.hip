@@ -204,7 +204,6 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_tiles(
 //                  (banded and block-structured matrices: all of them) the plan keeps col_ind a second time as 16-bit
 //                  offsets from the tile's smallest column; the tile adds its base (one scalar) back.  Wider tiles
 //                  (col_base < 0), overflow entries and the slow paths read col_ind itself.
-//   kFlavorUnit    every value 1 (val not read): y[r] = sum x[col_ind[j]]; second phase of the two-phase TJDS product
 //   kFlavorTjdsK   TJDS by rows: the stream lists, row by row, the TJDS positions p of the row's entries (`pos`) and
 //                  their permuted columns k (`col_ind`): value val[p] gathered from the jagged-diagonal array,
 //                  operand x_perm[k] (the one-kernel TJDS product, see ensure_row_gather in the engine)
@@ -241,6 +240,8 @@ struct OwnerExtra {
     const unsigned short *group_run;  // TjdsH: per tile and group of 32 entries, the run (inside the tile) of its first entry
     const int *run_ptr;             // TjdsH: ntiles + 1 bounds of the tiles' runs in run_tab
     const int *run_tab;             // TjdsH: per run {base of its block of 2^16 positions, start_pos of its diagonal} (cached: {column block, 0})
+    int unit_x;                     // TjdsH: the operand is the unit vector -- no x gather; overflow entries are POSITIONS in ovf_k (their
+                                    // values are read from val like everybody's: val changes from launch to launch, see the engine's TjdsSource)
     const unsigned short *row_rel;  // every row's first entry relative to the first entry of the tile it
                                     // starts in (2 B per row read by the product instead of row_ptr's 4); nullptr: row_ptr itself
     unsigned long long *stamps;     // STAMPED: per-wave {first, last} wall-clock ticks of this launch
@@ -255,6 +256,7 @@ struct OwnerArgs {
     const int *__restrict__ start_pos;
     const double *__restrict__ ovf_val;
     const int *__restrict__ ovf_k;
+    int unit_x;   // TjdsH: overflow entries are positions, the operand is 1 (OwnerExtra::unit_x)
 };
 
 // one entry's product the slow way (tile tails, overflow beyond one block width, giant rows)
@@ -263,8 +265,6 @@ __device__ __forceinline__ double owner_product_slow(const OwnerArgs &a, long lo
 {
     if constexpr (FLAVOR == kFlavorCsr || FLAVOR == kFlavorCsr16)
         return a.val[j] * a.x[a.col_ind[j]];
-    else if constexpr (FLAVOR == kFlavorUnit)
-        return a.x[a.col_ind[j]];
     else if constexpr (FLAVOR == kFlavorTjdsK)
         return a.val[a.pos[j]] * a.x[a.col_ind[j]];
     else {
@@ -278,7 +278,7 @@ template <int FLAVOR>
 __device__ __forceinline__ double owner_overflow_product(const OwnerArgs &a, int ovf_base, int e, int i)
 {
     if constexpr (FLAVOR == kFlavorTjdsS || FLAVOR == kFlavorTjdsH)
-        return a.ovf_val[ovf_base + i] * a.x[a.ovf_k[ovf_base + i]];
+        return a.unit_x ? a.val[a.ovf_k[ovf_base + i]] : a.ovf_val[ovf_base + i] * a.x[a.ovf_k[ovf_base + i]];
     else
         return owner_product_slow<FLAVOR>(a, (long long)e + i);
 }
@@ -319,7 +319,7 @@ __device__ __forceinline__ void owner_body(
     const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ tile_row,
     const int *__restrict__ tile_next, int rows, int nnz_arg, int ntiles, int tile_group_arg, const OwnerExtra &ex, const int block)
 {
-    const OwnerArgs a = {col_ind, val, x, ex.pos, ex.start_pos, ex.ovf_val, ex.ovf_k};
+    const OwnerArgs a = {col_ind, val, x, ex.pos, ex.start_pos, ex.ovf_val, ex.ovf_k, FLAVOR == kFlavorTjdsH ? ex.unit_x : 0};
     constexpr int TILE = kStreamBlock * VPT;
     constexpr int QCAP = (TILE + kStreamOver) / kLongRow + 1;
     constexpr bool CSR = FLAVOR == kFlavorCsr || FLAVOR == kFlavorCsr16;
@@ -498,9 +498,11 @@ __device__ __forceinline__ void owner_body(
             row_bounds(rlo + t + kStreamBlock, rp_a2, rp_b2);
         int co = 0;
         double vo = 0.0;
+        const bool unit_x = HALF && ex.unit_x;
         if (over0 && !(SMVP_TJDS_NEUTRALISE & 8)) {
-            vo = a.ovf_val[ovf_base + t];
             co = a.ovf_k[ovf_base + t];
+            if (!unit_x)
+                vo = a.ovf_val[ovf_base + t];
         }
         if (full_tile) {
             int slot[VPT];
@@ -536,10 +538,19 @@ __device__ __forceinline__ void owner_body(
                 else
                     v[k] = *src;
             }
+            double xo = 0.0;
+            if (unit_x) {  // second phase of the two-phase product: val holds products, the overflow entries' too (by position)
 #pragma unroll
-            for (int k = 0; k < VPT; ++k)
-                xk[k] = (SMVP_TJDS_NEUTRALISE & 1) ? 1.0 : a.x[c[k]];
-            const double xo = over0 && !(SMVP_TJDS_NEUTRALISE & 8) ? a.x[co] : 0.0;
+                for (int k = 0; k < VPT; ++k)
+                    xk[k] = 1.0;
+                if (over0)
+                    vo = a.val[co], xo = 1.0;
+            } else {
+#pragma unroll
+                for (int k = 0; k < VPT; ++k)
+                    xk[k] = (SMVP_TJDS_NEUTRALISE & 1) ? 1.0 : a.x[c[k]];
+                xo = over0 && !(SMVP_TJDS_NEUTRALISE & 8) ? a.x[co] : 0.0;
+            }
 #pragma unroll
             for (int k = 0; k < VPT; ++k)
                 prod[slot[k]] = v[k] * xk[k];
@@ -555,7 +566,7 @@ __device__ __forceinline__ void owner_body(
                         const int2 w = reinterpret_cast<const int2 *>(ex.run_tab)[ex.run_ptr[b] + r];
                         const int pw = w.x + (int)(w32 & 0xffffu);
                         const double vv = idx < in_place ? a.val[pw] : ex.val_cache[cache0 + (idx - in_place)];
-                        prod[m & ((1 << kSlotBits) - 1)] = vv * a.x[pw - w.y];
+                        prod[m & ((1 << kSlotBits) - 1)] = unit_x ? vv : vv * a.x[pw - w.y];
                     } else {
                         const int pw = a.pos[s + idx];
                         const double vv = idx < in_place ? a.val[pw] : ex.val_cache[cache0 + (idx - in_place)];
@@ -565,7 +576,7 @@ __device__ __forceinline__ void owner_body(
                 }
             }
             if (over0)
-                po = vo * a.x[co];
+                po = unit_x ? a.val[co] : vo * a.x[co];
         }
     } else if (whole) {
         if (rlo + t < rhi)  // this lane's first row in phase 2
@@ -597,8 +608,8 @@ __device__ __forceinline__ void owner_body(
         const double xo = over0 ? a.x[co] : 0.0;
 #pragma unroll
         for (int k = 0; k < VPT; ++k)
-            p[k] = FLAVOR == kFlavorUnit ? xk[k] : v[k] * xk[k];
-        po = FLAVOR == kFlavorUnit ? xo : vo * xo;
+            p[k] = v[k] * xk[k];
+        po = vo * xo;
     } else {
 #pragma unroll
         for (int k = 0; k < VPT; ++k)
@@ -1136,7 +1147,7 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
     ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_val = l.ovf_val, ex.ovf_k = l.ovf_k;
     ex.cache_ptr = l.cache_ptr, ex.val_cache = l.val_cache;
     ex.col16 = l.col16, ex.col_base = l.col_base;
-    ex.word32 = l.word32, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_tab = l.run_tab;
+    ex.unit_x = l.unit_x, ex.word32 = l.word32, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_tab = l.run_tab;
     ex.stamps = l.stamps;
     ex.row_rel = l.row_rel;
 #define SMVP_OWNER_ST(V, F, S)                                                                                     \
@@ -1155,9 +1166,6 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
     SMVP_OWNER(8, kFlavorCsr)
     SMVP_OWNER(4, kFlavorCsr16)
     SMVP_OWNER(8, kFlavorCsr16)
-    SMVP_OWNER(1, kFlavorUnit)
-    SMVP_OWNER(4, kFlavorUnit)
-    SMVP_OWNER(8, kFlavorUnit)
     SMVP_OWNER(1, kFlavorTjdsK)
     SMVP_OWNER(4, kFlavorTjdsK)
     SMVP_OWNER(8, kFlavorTjdsK)
@@ -1227,7 +1235,7 @@ hipError_t launch_csr_stream_owner_repeat(int vpt, int flavor, const OwnerLaunch
     ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_val = l.ovf_val, ex.ovf_k = l.ovf_k;
     ex.cache_ptr = l.cache_ptr, ex.val_cache = l.val_cache;
     ex.col16 = l.col16, ex.col_base = l.col_base;
-    ex.word32 = l.word32, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_tab = l.run_tab;
+    ex.unit_x = l.unit_x, ex.word32 = l.word32, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_tab = l.run_tab;
     ex.stamps = nullptr;
     ex.row_rel = l.row_rel;
     RepeatCtl ctl;
