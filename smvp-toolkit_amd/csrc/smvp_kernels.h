@@ -66,6 +66,9 @@ int owner_stamp_slots(int ntiles, int flavor);  // {first, last} tick pairs one 
 // l.stamps, ctl_words = kRepeatCtlWords unsigned of device memory; *top bit 31 set afterwards = the launch gave up (abort)
 constexpr int kRepeatCtlWords = 32 * 65;  // 32 shard counters, 32 go words, the top counter (bit 31: abort; the last line), each on a 128-byte line of its own
 int owner_repeat_grid(int vpt, int flavor, int ntiles);
+// (the CSR flavours' plain launches live in the second translation unit of smvp_kernels.hip, compiled -DSMVP_TU_ILP with the
+// max-ILP scheduling strategy -- see the Makefile; `extra` is the launcher's OwnerExtra)
+hipError_t launch_owner_csr_ilp(int vpt, int flavor, const OwnerLaunch &l, const void *extra, unsigned grid_x, int group, hipStream_t stream);
 hipError_t launch_csr_stream_owner_repeat(int vpt, int flavor, const OwnerLaunch &l, int reps, int grid, unsigned *ctl_words,
                                           hipStream_t stream);
 hipError_t launch_stamp_reduce(const unsigned long long *stamps, int slots_per_product, int products,

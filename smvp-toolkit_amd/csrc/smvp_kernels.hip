@@ -48,6 +48,7 @@ __device__ __forceinline__ int tile_of_block(int block, int group)
     return (seq / group) * (8 * group) + xcd * group + seq % group;
 }
 
+#ifndef SMVP_TU_ILP
 // ---------------------------------------------------------------------------
 // K1: CSR, one sub-wavefront of T lanes per row, __shfl_down sums.
 // T = 64 is the classic wavefront-per-row kernel; smaller T packs 64/T rows
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_tiles(
     }
 }
 
+#endif  // !SMVP_TU_ILP
 // ---------------------------------------------------------------------------
 // K2': the same tiles, but the tile in which a row STARTS finishes that row
 // itself: it also loads the few entries past its end that belong to its last
@@ -286,6 +288,9 @@ __device__ __forceinline__ double owner_overflow_product(const OwnerArgs &a, int
 // Diagnostic builds only (make HIPFLAGS+=-DSMVP_PHASE_STAMPS): where a workgroup of the owner kernel spends its time.
 // Thread 0 of every workgroup adds the 100 MHz wall-clock ticks between its phase boundaries to six global counters;
 // smvp_debug_phase_stamps() (engine) prints and clears them.  The normal build contains none of this.
+#if defined(SMVP_PHASE_STAMPS) && defined(SMVP_TU_ILP)
+#undef SMVP_PHASE_STAMPS   // (the diagnostic build runs every flavour in the other unit)
+#endif
 #ifdef SMVP_PHASE_STAMPS
 __device__ unsigned long long g_owner_phase[8];
 #define SMVP_PHASE(n)                                                                        \
@@ -748,6 +753,7 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
                                      (int)blockIdx.x);
 }
 
+#ifndef SMVP_TU_ILP
 // ---------------------------------------------------------------------------
 // K2-repeat: `reps` products in ONE launch, each with a window of its own -- for the reference's own use case, -n 1000 on a
 // matrix that lives in the caches (main-cli.c:402-420: the same product, the same x, n times).  A launch boundary costs such
@@ -1161,11 +1167,18 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
             SMVP_OWNER_ST(V, F, false);   \
         return hipGetLastError();         \
     }
+#ifdef SMVP_PHASE_STAMPS   // (diagnostic builds keep every flavour here: one set of phase counters)
     SMVP_OWNER(1, kFlavorCsr)
     SMVP_OWNER(4, kFlavorCsr)
     SMVP_OWNER(8, kFlavorCsr)
     SMVP_OWNER(4, kFlavorCsr16)
     SMVP_OWNER(8, kFlavorCsr16)
+#else
+    // the CSR flavours are compiled in the second translation unit of this file (SMVP_TU_ILP: the max-ILP scheduling strategy
+    // suits them -- memplus x944 0.2866 -> 0.2800 ms -- and costs the TJDS flavours 2-3 %)
+    if (flavor == kFlavorCsr || flavor == kFlavorCsr16)
+        return launch_owner_csr_ilp(vpt, flavor, l, &ex, grid.x, group, stream);
+#endif
     SMVP_OWNER(1, kFlavorTjdsK)
     SMVP_OWNER(4, kFlavorTjdsK)
     SMVP_OWNER(8, kFlavorTjdsK)
@@ -1345,6 +1358,33 @@ hipError_t launch_fill(double *p, double v, long long n, hipStream_t stream)
     return hipGetLastError();
 }
 
+#else  // SMVP_TU_ILP: the plain launches of the CSR flavours (launch_csr_stream_owner in the other unit prepares `extra`, grid and group)
+hipError_t launch_owner_csr_ilp(int vpt, int flavor, const OwnerLaunch &l, const void *extra, unsigned grid_x, int group, hipStream_t stream)
+{
+    const OwnerExtra &ex = *static_cast<const OwnerExtra *>(extra);
+    const dim3 grid(grid_x);
+#define SMVP_OWNER_ST(V, F, S)                                                                                     \
+    hipLaunchKernelGGL((csr_stream_owner<V, F, S>), grid, dim3(kStreamBlock), 0, stream, l.row_ptr, l.col_ind, l.val, \
+                       l.x, l.y, l.tile_row, l.tile_next, l.rows, l.nnz, l.ntiles, group, ex)
+#define SMVP_OWNER(V, F)                  \
+    if (vpt == V && flavor == F) {        \
+        if (l.stamps)                     \
+            SMVP_OWNER_ST(V, F, true);    \
+        else                              \
+            SMVP_OWNER_ST(V, F, false);   \
+        return hipGetLastError();         \
+    }
+    SMVP_OWNER(1, kFlavorCsr)
+    SMVP_OWNER(4, kFlavorCsr)
+    SMVP_OWNER(8, kFlavorCsr)
+    SMVP_OWNER(4, kFlavorCsr16)
+    SMVP_OWNER(8, kFlavorCsr16)
+#undef SMVP_OWNER
+#undef SMVP_OWNER_ST
+    return hipErrorInvalidValue;
+}
+#endif  // SMVP_TU_ILP
+
 }  // namespace smvp
 
 // ---------------------------------------------------------------------------
@@ -1370,6 +1410,7 @@ hipError_t launch_fill(double *p, double v, long long n, hipStream_t stream)
 // ---------------------------------------------------------------------------
 namespace smvp {
 
+#ifdef SMVP_TU_ILP   // (max-ILP scheduling: config 4's structure 1.767 -> 1.60 ms)
 // One iteration of a wavefront takes G chunks of its strip (G * 256 entries, G * 4 per lane): all their gathers are in
 // flight together, the plan words of the next iteration are requested before the sums are touched, and the chunks are
 // then added one after the other (a chunk's turns are counted inside the chunk, so this keeps every row in order).
@@ -1519,6 +1560,7 @@ hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, con
     return hipGetLastError();
 }
 
+#else  // !SMVP_TU_ILP
 // How scattered are the gathers of a CSR matrix?  Sample s of `samples` looks at kSpreadSpan consecutive entries --
 // what one XCD's turn of 64 tiles of the tile kernel gathers -- and counts the distinct 128-byte lines of x they touch,
 // by linear counting: every line sets one hashed bit of a 512 Kbit LDS map; the host turns the number of set bits into
@@ -1561,5 +1603,7 @@ hipError_t launch_csr_line_spread(const int *col_ind, long long nnz, int samples
     hipLaunchKernelGGL(csr_line_spread, dim3(samples), dim3(1024), 0, stream, col_ind, nnz, samples, set_bits);
     return hipGetLastError();
 }
+
+#endif  // SMVP_TU_ILP
 
 }  // namespace smvp
