@@ -1,0 +1,402 @@
+"""bench_core.py -- what bench.py's headline needs: the timed region, the workload builder, the headline product's measurement,
+its roofline object, and the launcher of `--gpus N` without a launcher.  No torch import at module level (spawn_ranks must run
+before torch or HIP are touched).  bench.py is the contract (flags, order of the legs, the compact line); bench_legs.py holds the
+secondary legs and the detail file."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+BENCH_SCRIPT = os.path.join(ROOT, "bench.py")      # what child processes run (ranks, --pmc passes, the C-layer child)
+sys.path.insert(0, os.path.join(ROOT, "smvp-toolkit_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+TOL = 1e-9              # row-normwise: |dy| <= TOL * sum_j |a_rj x_j|
+
+
+def log(rank, *a):
+    if rank == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+# Untimed products in front of a leg's timed region.  A leg follows seconds of host work (building and checking its matrix),
+# and the first milliseconds of device work after such a pause run slower than the steady state (measured: the random-model
+# leg read 0.677 ms with 3 warm-up products and 50 timed ones, 0.650 ms with 20 and 200 in the same process on the same box,
+# profiles/r04_binned_measured.txt section 13; round 5: whichever of the headline's two timed regions came first behind the
+# driver's --warmup 5 = 1.5 ms read 7 % slower than the other -- 0.310-0.321 against 0.291-0.294 ms): every leg runs about
+# PREWARM_MS of untimed products first (prewarm); the W warm-up steps the contract names come on top, in front of the K timed steps.
+PREWARM_MS = 40.0  # the headline leg: untimed products in front of its two timed regions (the W warm-up steps of the contract come on top)
+WARM_SHORT = 20   # products of < 1 ms
+WARM_LONG = 8     # products of a few ms (config 4)
+
+
+def timed_region(torch, dist, world, steps, body):
+    """barrier + sync, `steps` x body(), sync + barrier -> (wall seconds, HIP-event ms), both MAX over ranks."""
+    import gc
+
+    collecting = gc.isenabled()
+    gc.disable()        # no collector pause between the two clock readings
+    try:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            body()
+        e1.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        wall = time.perf_counter() - t0
+    finally:
+        if collecting:
+            gc.enable()
+    ev_ms = e0.elapsed_time(e1)
+    if world > 1:
+        t = torch.tensor([wall, ev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, ev_ms = float(t[0]), float(t[1])
+    return wall, ev_ms
+
+
+def prewarm(torch, body, ms=None):
+    """About `ms` (default PREWARM_MS) of untimed device work in front of a leg's timed region: three probe runs timed with a
+    HIP event pair, then as many more as fill the time (at most 400)."""
+    ms = PREWARM_MS if ms is None else ms
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        body()
+    e1.record()
+    torch.cuda.synchronize()
+    each = max(e0.elapsed_time(e1) / 3.0, 1e-3)
+    for _ in range(int(min(400, max(0, ms / each - 3)))):
+        body()
+
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def golden_file(kind, name):
+    """Plain path of a committed data fixture (tests/golden/<kind>/<name>[.gz]); .gz files are inflated once into a
+    per-user temp dir.  Ranks may race here: each writes its own temp file and renames it into place."""
+    import gzip
+    import shutil
+    import tempfile
+
+    plain = os.path.join(GOLDEN, kind, name)
+    if os.path.exists(plain):
+        return plain
+    cache = os.path.join(tempfile.gettempdir(), "smvp_bench_cache_%d" % os.getuid())
+    os.makedirs(cache, exist_ok=True)
+    out = os.path.join(cache, name)
+    if not os.path.exists(out):
+        fd, tmp = tempfile.mkstemp(prefix=name + ".", dir=cache)
+        with gzip.open(plain + ".gz", "rb") as src, os.fdopen(fd, "wb") as dst:
+            shutil.copyfileobj(src, dst)
+        os.replace(tmp, out)
+    return out
+
+
+def report_y_lines(name):
+    lines = open(golden_file("reports", name)).read().split("\n")
+    return lines[lines.index("[") + 1:lines.index("]")]
+
+
+def build_block(sm, sharding, workload, args, rank, world):
+    """This rank's row block of the workload -> dict with host CSR arrays and a description."""
+    t0 = time.perf_counter()
+    if workload in ("memplus_tiled", "pwt_tiled"):
+        base_name, base_report, base_copies = (("memplus.mtx", "smvp-toolbox_report_CSR_1615284663.txt", 944) if workload == "memplus_tiled"
+                                               else ("pwt.mtx", "smvp-toolbox_report_CSR_1615284671.txt", 459))
+        tc, m, n, coo = sm.mm_read_coo(golden_file("sample-data", base_name))
+        rp, ci, v = sm.csr_from_coo(coo, m)
+        total = (getattr(args, "copies", 0) or base_copies) * (world if getattr(args, "scaling", "strong") == "weak" else 1)
+        copies = total - total % world if total >= world else world
+        c0, c1 = copies * rank // world, copies * (rank + 1) // world
+        row_ptr, col_ind, val = sharding.tile_block_diagonal(rp, ci, v, n, c0, c1)
+        blk = dict(rows_total=m * copies, cols_total=n * copies, r0=m * c0, r1=m * c1,
+                   bounds=np.array([m * (copies * g // world) for g in range(world + 1)], dtype=np.int64),
+                   name=("memplus.mtx x%d block-diagonal (kron(I_%d, memplus)) -- the exact-structure substitute for the "
+                         "SURVEY 8(d) random memplus-shaped model, which is in extra.survey_random_model" % (copies, copies))
+                   if workload == "memplus_tiled" else
+                   "pwt.mtx x%d block-diagonal (kron(I_%d, pwt), stored triangle only like the reference)" % (copies, copies),
+                   base=(m, n, rp, ci, v, c1 - c0, base_report))
+    else:
+        if workload == "memplus_shaped":
+            kind, seed, param = sm.SYNTH_MEMPLUS_SHAPED, 12345, 0
+            rows_total = cols_total = (1 << args.rows_log2) * (world if getattr(args, "scaling", "strong") == "weak" else 1)
+            name = "memplus_shaped random model (SURVEY 8(d)) rows=%d seed=%d" % (rows_total, seed)
+        else:
+            kind, seed, param = sm.SYNTH_UNIFORM, 2024, 32
+            rows_total = cols_total = args.rows * (world if getattr(args, "scaling", "strong") == "weak" else 1)
+            name = "uniform 32 entries/row rows=%d seed=%d" % (rows_total, seed)
+        bounds = sharding.equal_row_bounds(rows_total, world)
+        r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+        row_ptr, col_ind, val = sm.synth_csr(kind, seed, rows_total, cols_total, param, r0, r1,
+                                             threads=max(1, min(16, (os.cpu_count() or 8) // max(1, world))))
+        blk = dict(rows_total=rows_total, cols_total=cols_total, r0=r0, r1=r1, name=name, base=None, bounds=bounds)
+    blk.update(row_ptr=row_ptr, col_ind=col_ind, val=val, nnz=int(row_ptr[-1]), rows=blk["r1"] - blk["r0"])
+    log(rank, "%s: rows [%d, %d), %d entries, built in %.1f s" % (blk["name"], blk["r0"], blk["r1"], blk["nnz"],
+                                                                  time.perf_counter() - t0))
+    return blk
+
+
+def host_check(blk, x_host, got):
+    """Independent host computation of this block's y (numpy, not the oracle); returns (ok, worst, scale)."""
+    row_ptr, col_ind, val = blk["row_ptr"], blk["col_ind"], blk["val"]
+    nonempty = np.diff(row_ptr) > 0
+    prod = val * x_host[col_ind]
+    starts = np.minimum(row_ptr[:-1], max(len(prod) - 1, 0))
+    host = np.add.reduceat(prod, starts) * nonempty if len(prod) else np.zeros(blk["rows"])
+    scale = np.add.reduceat(np.abs(prod), starts) * nonempty if len(prod) else np.zeros(blk["rows"])
+    err = np.abs(got - host)
+    return bool(np.all(err <= TOL * scale)), float((err / np.maximum(scale, 1e-300)).max()), scale
+
+
+def _value_cache(T, nnz):
+    """The TJDS product's value cache: val lines shared by `min_tiles` tiles or more keep a tile-ordered second copy."""
+    min_tiles, cached = T.get_value_cache()
+    return {"min_tiles": min_tiles, "cached_share": round(cached / max(1, nnz), 4)}
+
+
+def measure_csr(torch, dist, sm, sharding_mod, blk, args, world, local_rank, rank, steps, warmup, collective):
+    """Upload the block, check it, time `steps` products (+ all-gather), then the kernel alone."""
+    fmt = getattr(args, "format", "csr")
+    if fmt == "csr":
+        d_row_ptr = torch.from_numpy(blk["row_ptr"]).cuda()
+        d_col_ind = torch.from_numpy(blk["col_ind"]).cuda()
+        d_val = torch.from_numpy(blk["val"]).cuda()
+        A = sm.CsrMatrix(blk["rows"], blk["cols_total"], d_row_ptr, d_col_ind, d_val, device=local_rank, first_row=blk["r0"])
+        if args.kernel != "auto" or args.kernel_param:
+            A.set_kernel({"auto": 0, "vector": 1, "stream": 2, "stream-carry": 3, "colsweep": 4, "binned": 5}[args.kernel], args.kernel_param)
+    else:   # TJDS of this rank's row block, built on the GPU from the block's entries
+        coo = np.zeros(blk["nnz"], dtype=sm.COO_DTYPE)
+        coo["row"] = np.repeat(np.arange(blk["rows"], dtype=np.int32), np.diff(blk["row_ptr"]))
+        coo["col"], coo["val"] = blk["col_ind"], blk["val"]
+        d_coo = torch.from_numpy(coo.view(np.uint8)).cuda()
+        del coo
+        d_row_ptr = d_col_ind = d_val = None
+        A = sm.TjdsMatrix(sm.tjds_from_coo_device(d_coo, blk["rows"], blk["cols_total"], blk["nnz"]), device=local_rank)
+        del d_coo
+    kernel_name, alg_bytes = A.describe()
+    launches = A.launches() if fmt == "csr" else 1
+    pi = A.plan_info()
+    plan = {"plan_bytes": pi["plan_bytes"], "matrix_bytes": pi["matrix_bytes"],
+            "plan_over_matrix": round(pi["plan_bytes"] / max(1.0, pi["matrix_bytes"]), 3), "plan_build_ms": round(pi["build_ms"], 1)}
+    if fmt == "tjds":
+        plan["value_cache"] = _value_cache(A, blk["nnz"])
+
+    x_host = np.ones(blk["cols_total"]) if args.x == "ones" else np.random.default_rng(67890).random(blk["cols_total"])
+    d_x = torch.from_numpy(x_host).cuda()
+    d_y_full = torch.zeros(blk["rows_total"], dtype=torch.float64, device="cuda")
+    # one rank: the product writes the full vector; several: each rank's block has its own buffer and the
+    # all-gather assembles the full y on every GPU (no aliasing between send and receive buffers)
+    d_y = d_y_full if not (world > 1 or dist.is_initialized()) else torch.zeros(blk["rows"], dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream()
+    gather = collective and (world > 1 or dist.is_initialized())
+
+    if fmt == "tjds":
+        A.set_x(d_x, stream=stream)      # the operand permutation is set-up, like main-cli.c:907-923
+
+    def spmv_only():
+        if fmt == "csr":
+            A.spmv(d_x, d_y, stream=stream)
+        else:
+            A.spmv(d_y, stream=stream)
+
+    bounds = blk["bounds"]
+
+    def step():
+        spmv_only()
+        if gather:      # equal row blocks: one all_gather_into_tensor straight into the full y
+            sharding_mod.allgather_y(dist, d_y, d_y_full, bounds)
+
+    # correctness gate before any timing
+    step()
+    torch.cuda.synchronize()
+    got = d_y.cpu().numpy()
+    ok, worst, scale = host_check(blk, x_host, got)
+    if not ok:
+        raise SystemExit("rank %d: product is wrong on %s (max normwise error %g)" % (rank, blk["name"], worst))
+    golden = None
+    if blk["base"] is not None and args.x == "ones":
+        # full-size parity against the reference's own golden vector: y must be tile(y_memplus), and y_memplus is
+        # printed with "%g" in the committed report output-test/smvp-toolbox_report_CSR_1615284663.txt.  No oracle
+        # here: the base product runs on the GPU too and is compared with the report's text.
+        m, n, rp, ci, v, ncopies, base_report = blk["base"]
+        B = sm.CsrMatrix(m, n, rp, ci, v, device=local_rank)
+        d_yb = torch.empty(m, dtype=torch.float64, device="cuda")
+        B.spmv(d_x[:n], d_yb, stream=stream)
+        torch.cuda.synchronize()
+        B.close()
+        y_base = d_yb.cpu().numpy()
+        want = report_y_lines(base_report)
+        sc = np.add.reduceat(np.abs(v), rp[:-1])
+        short = np.diff(rp) <= 32                       # summed left to right by one lane: bit-exact => same "%g" text
+        text_ok = all(("%g" % y_base[i]) == want[i] for i in np.flatnonzero(short))
+        num_ok = bool(np.all(np.abs(y_base - np.array([float(s) for s in want])) <= 1e-5 * sc + 1e-300))
+        tiles_ok = bool(np.all(np.abs(got.reshape(ncopies, m) - y_base[None, :]) <= TOL * sc[None, :]))
+        if not (text_ok and num_ok and tiles_ok):
+            raise SystemExit("rank %d: y is not tile(y of the committed report %s)" % (rank, base_report))
+        golden = {"y_equals_tiled_reference_memplus_y" if "1615284663" in base_report else "y_equals_tiled_reference_pwt_y": True,
+                  "report_text_equal_on_rows_upto_32_entries": int(short.sum()), "rows_per_copy": int(m)}
+    if gather:
+        chk = float(d_y_full.sum().item())
+        t = torch.tensor([chk, -chk], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if float(t[0]) != -float(t[1]):
+            raise SystemExit("all-gathered y differs between ranks")
+    log(rank, "correct: max |dy| / sum|a x| = %.2e over %d local rows (%s)" % (worst, blk["rows"], kernel_name))
+
+    # the kernel alone first (HIP events on the launch stream, no collective), then the W warm-up steps and the K timed steps of
+    # the contract: the first milliseconds of device work after the seconds of host work above run slower than the steady state
+    # (prewarm), and W is the caller's -- the driver asks for 5 steps = 1.5 ms
+    prewarm(torch, spmv_only)
+    _, k_ms = timed_region(torch, dist, world, steps, spmv_only)
+    for _ in range(warmup):
+        step()
+    wall, _ = timed_region(torch, dist, world, steps, step)
+
+    tot = torch.tensor([blk["nnz"], alg_bytes], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tot)
+    res = dict(kernel=kernel_name, launches=launches, alg_bytes_local=alg_bytes, alg_bytes_total=float(tot[1]), nnz_total=float(tot[0]),
+               wall_per_step=wall / steps, kernel_ms=k_ms / steps, worst=worst, golden=golden, scale=scale, got=got, plan=plan,
+               x_host=x_host, d_x=d_x, d_y=d_y, A=A, keep=(d_row_ptr, d_col_ind, d_val, d_y_full))
+    return res
+
+
+def recorded_traffic(workload, kernel, alg_bytes):
+    """HBM bytes per launch from the committed PMC passes (profiles/*traffic.json), if one matches this run.
+
+    PMC counters cannot be read from inside the benchmark; tools/profile_bench.sh collects them in separate
+    rocprofv3 --pmc passes over this same command and the summary is committed under profiles/.
+    """
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        same_launch = abs(t.get("alg_bytes_per_launch", 0) - alg_bytes) <= 0.01 * alg_bytes
+        if (str(t.get("workload"))[:30] == workload[:30] and t.get("kernel") == kernel and same_launch
+                and t.get("traffic_bytes_per_launch")):
+            best = (t["traffic_bytes_per_launch"], os.path.basename(f))
+    return best
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no RANK / WORLD_SIZE in the environment -- the way
+    the driver starts the scaling runs): this process becomes the launcher.  BEFORE importing torch or touching HIP in
+    any way it starts the N ranks as child processes of its own -- this same script with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT set, each the leader of its own process group -- relays rank 0's stdout (the one
+    JSON line), lets every rank's stderr through, waits under a wall-clock budget and returns the worst exit code.  Never
+    os.exec*.  When a rank dies the others are given a short grace (they would wait for it in a collective for ever) and are
+    then ended -- by the exact process groups started here.  The torch.distributed.run path stays as it was."""
+    import signal
+    import socket
+    import subprocess
+
+    n = args.gpus
+    with socket.socket() as s:      # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC")}
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), SMVP_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, BENCH_SCRIPT] + list(argv)
+    log(0, "--gpus %d without a launcher: starting %d rank processes (rendezvous 127.0.0.1:%d, budget %.0f s)" % (n, n, port, args.launch_budget))
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0", ROLE_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True if r == 0 else None,
+                                      start_new_session=True))
+
+    def end(p):
+        if p.poll() is None:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)     # the process group this rank was started as (its own children too)
+            except Exception:
+                try:
+                    p.kill()
+                except Exception:
+                    pass
+
+    import threading
+
+    lines = []
+
+    def relay():        # rank 0's stdout, line by line as it comes
+        for l in procs[0].stdout:
+            lines.append(l)
+            sys.stdout.write(l)
+            sys.stdout.flush()
+
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    deadline = time.time() + args.launch_budget
+    grace = None
+    why = ""
+    stragglers = []
+    while any(p.poll() is None for p in procs):
+        now = time.time()
+        failed = [i for i, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if failed and grace is None:
+            grace = now + 30.0
+            why = "rank %d exited with %s" % (failed[0], procs[failed[0]].returncode)
+        if procs[0].poll() == 0 and grace is None:
+            # rank 0 is done and has printed its line: the others have nothing left to do but leave (they finish before rank 0
+            # does -- rank 0 alone runs the C-layer child at the end); one still there after 30 s is ended, the line stands
+            grace = now + 30.0
+            why = "rank 0 finished; rank(s) still running 30 s later were ended"
+        if now > deadline or (grace is not None and now > grace):
+            why = why or "the ranks did not finish within --launch-budget %.0f s" % args.launch_budget
+            stragglers = [i for i, p in enumerate(procs) if p.poll() is None]
+            for p in procs:
+                end(p)
+            break
+        time.sleep(0.1)
+    for p in procs:
+        try:
+            p.wait(timeout=15)
+        except Exception:
+            end(p)
+    t.join(timeout=10)
+    codes = [p.returncode if p.returncode is not None else -9 for p in procs]
+    have_line = any(l.startswith("{") for l in lines)
+    if codes[0] == 0 and have_line and all(c == 0 or i in stragglers for i, c in enumerate(codes)):
+        if stragglers:
+            log(0, "self-launched run: %s (ranks %s); rank 0's line stands" % (why, stragglers))
+        return 0
+    rc = 0 if all(c == 0 for c in codes) else next((c for c in codes if c > 0), 1)
+    if rc == 0 and not have_line:
+        why, rc = "rank 0 printed no JSON line", 1
+    if rc:
+        log(0, "self-launched run failed (%s); exit codes by rank: %s" % (why or "non-zero exit", codes))
+    return rc
+
+
+def roofline_of(res, workload=None):
+    achieved = res["alg_bytes_local"] / (res["kernel_ms"] * 1e-3) * 1e-9
+    r = {"bound": "hbm", "kernel": res["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+         "alg_bytes_per_launch": res["alg_bytes_local"] / res.get("launches", 1),
+         "ms_per_launch": round(res["kernel_ms"] / res.get("launches", 1), 5), "launches_per_product": res.get("launches", 1),
+         "ms_per_product": round(res["kernel_ms"], 5), "plan": res.get("plan"),
+         "note": "frac = SURVEY 8(d) algorithmic bytes / HIP-event time per launch / 8 TB/s; moved_* = bytes the PMC counters saw" +
+                 ("; 16-bit column offsets: traffic can lie below the algorithmic bytes" if ", 5, " in res["kernel"] else "")}
+    rec = recorded_traffic(workload, res["kernel"], res["alg_bytes_local"]) if workload else None
+    if rec:
+        r["traffic"] = rec[0]
+        r["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" % rec[1]
+    return r

@@ -386,6 +386,9 @@ typedef struct smvp_run_opts {
     int tjds_mode;      /* SMVP_TJDS_MODE_* for smvp_tjds_compute (AUTO = ROW_GATHER) */
     int timing;         /* SMVP_TIMING_*: how each product is timed */
     int shard_exchange; /* ngpus > 1: SMVP_EXCHANGE_* (default AUTO; COPIES / DIRECT: ngpus may exceed the visible GPUs -- virtual ranks) */
+    int repeat_patience_us; /* SMVP_TIMING_DEVICE, the repeating kernel: microseconds a workgroup waits at the barrier between two
+                           products before the launch gives up and the run falls back to one launch per product (0 = 50 000;
+                           negative = none at all: whoever has to wait gives up -- the fallback's test) */
     const double *x;    /* host operand, NULL = all ones (main-cli.c:368-369) */
 } smvp_run_opts_t;
 void smvp_run_opts_default(smvp_run_opts_t *o);
@@ -407,7 +410,8 @@ typedef struct smvp_run_info {
     double device_clock_khz; /* DEVICE: rate of the clock the times were taken with */
     int repeat_launches;   /* DEVICE: launches of the repeating kernel it took -- up to 1024 products per launch, every product's
                               window stamped between device-side barriers (0: one launch per product) */
-    int reserved;
+    int repeat_gave_up;    /* DEVICE: 1 = a launch of the repeating kernel gave up at a barrier (its grid was not resident as a whole) and
+                              the run was done over, one launch per product */
 } smvp_run_info_t;
 int smvp_last_run_info(smvp_run_info_t *out);
 

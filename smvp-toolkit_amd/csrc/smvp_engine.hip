@@ -865,13 +865,13 @@ static int csr_repeat_grid(const smvp_csr_t *h)
 }
 
 static int csr_spmv_repeat(smvp_csr_t *h, const double *d_x, double *d_y, void *stream, unsigned long long *stamps, int reps, int grid,
-                           unsigned *ctl_words)
+                           unsigned *ctl_words, bool first_of_run, unsigned long long patience)
 {
     DeviceScope on(h->device);
-    smvp::OwnerLaunch l;
+    smvp::OwnerLaunch l{};
     fill_owner_launch(h, d_x, d_y, stamps, &l);
     const hipError_t e = smvp::launch_csr_stream_owner_repeat(h->vpt, h->d_col16 ? smvp::kFlavorCsr16 : h->flavor, l, reps, grid, ctl_words,
-                                                              (hipStream_t)stream);
+                                                              first_of_run, patience, (hipStream_t)stream);
     if (e != hipSuccess)
         return smvp::fail(SMVP_ERR_HIP, "repeating CSR launch failed: %s", hipGetErrorString(e));
     return SMVP_OK;
@@ -944,7 +944,7 @@ static int csr_spmv_impl(smvp_csr_t *h, const double *d_x, double *d_y, void *st
     else if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
         e = smvp::launch_csr_vector(h->lanes_per_row, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y, h->rows, st);
     else if (h->kernel == SMVP_CSR_KERNEL_STREAM) {
-        smvp::OwnerLaunch l;
+        smvp::OwnerLaunch l{};
         fill_owner_launch(h, d_x, d_y, stamps, &l);
         e = smvp::launch_csr_stream_owner(h->vpt, h->d_col16 ? smvp::kFlavorCsr16 : h->flavor, l, st);
     } else
@@ -1697,6 +1697,8 @@ int run_timed_products(RunScratch &s, int rows, int iters, const smvp_run_opts_t
     g_last_run.timing = stamped ? SMVP_TIMING_DEVICE : SMVP_TIMING_EVENTS;
     g_last_run.graph_replays = 0;
     g_last_run.repeat_launches = 0;
+    g_last_run.repeat_gave_up = 0;
+    const unsigned long long patience = smvp::repeat_patience_ticks(o->repeat_patience_us);
     HIP_TRY(hipStreamSynchronize(s.stream));
     const double t0 = host_ms();
     bool repeated = false;
@@ -1712,8 +1714,11 @@ int run_timed_products(RunScratch &s, int rows, int iters, const smvp_run_opts_t
     if (stamped && repeat_grid > 0 && o->timing != SMVP_TIMING_DEVICE_GRAPH) {
         // Up to kRepeatRing products per launch of the repeating kernel, the launches of a run enqueued one behind the other:
         // every launch's windows are reduced on the device into first_last[product] and its give-up word is set aside; the
-        // host waits once per kRepeatSuper products.  A launch that gave up at one of its barriers (the grid was not resident
-        // as a whole: another process on the device) sends the whole run to the single launches below.
+        // host waits once per kRepeatSuper products -- and once for the FIRST launch of the run, before it queues any other.  A
+        // launch that gave up at one of its barriers (the grid was not resident as a whole: another stream, thread or process on
+        // the device -- the occupancy query the grid was sized from knows nothing of those) sends the whole run to the single
+        // launches below: it has waited `repeat_patience_us` (50 ms) at most, and launches queued behind it read the run's
+        // sticky give-up word and leave as they start.
         constexpr int kRepeatRing = 1024, kRepeatSuper = 1 << 20;
         StampTimer st;
         unsigned *d_tops = nullptr;
@@ -1735,11 +1740,22 @@ int run_timed_products(RunScratch &s, int rows, int iters, const smvp_run_opts_t
             int launches = 0;
             for (int i0 = 0; i0 < ns; i0 += ring, ++launches) {
                 const int n = std::min(ring, ns - i0);
-                if (int rc = repeat(xc, yc, st.d_stamps, n, repeat_grid, st.d_ctl))
+                const bool first_of_run = s0 == 0 && i0 == 0;
+                if (int rc = repeat(xc, yc, st.d_stamps, n, repeat_grid, st.d_ctl, first_of_run, patience))
                     return rc;
                 HIP_TRY(smvp::launch_stamp_reduce(st.d_stamps, slots, n, st.d_first_last + 2 * (size_t)i0, s.stream));
                 HIP_TRY(hipMemcpyAsync(d_tops + launches, st.d_ctl + smvp::kRepeatCtlWords - 32, sizeof(unsigned), hipMemcpyDeviceToDevice, s.stream));
+                if (first_of_run && ns > n) {  // more launches would follow: has this one held?
+                    HIP_TRY(hipMemcpyAsync(tops.data(), d_tops, sizeof(unsigned), hipMemcpyDeviceToHost, s.stream));
+                    HIP_TRY(hipStreamSynchronize(s.stream));
+                    if (tops[0] & 0x80000000u) {
+                        repeated = false;
+                        break;
+                    }
+                }
             }
+            if (!repeated)
+                break;
             HIP_TRY(hipMemcpyAsync(fl.data(), st.d_first_last, sizeof(unsigned long long) * 2 * (size_t)ns, hipMemcpyDeviceToHost, s.stream));
             HIP_TRY(hipMemcpyAsync(tops.data(), d_tops, sizeof(unsigned) * (size_t)launches, hipMemcpyDeviceToHost, s.stream));
             HIP_TRY(hipStreamSynchronize(s.stream));
@@ -1752,8 +1768,10 @@ int run_timed_products(RunScratch &s, int rows, int iters, const smvp_run_opts_t
             for (int k = 0; k < ns; ++k)
                 s.ms[(size_t)(s0 + k)] = (double)(fl[2 * (size_t)k + 1] - fl[2 * (size_t)k]) / (double)khz;
         }
-        if (!repeated)
+        if (!repeated) {
             g_last_run.repeat_launches = 0;
+            g_last_run.repeat_gave_up = 1;
+        }
         s.d_result = yc;
     }
     if (stamped && !repeated) {
@@ -1945,8 +1963,8 @@ extern "C" int smvp_csr_compute(const smvp_coo_t *coo, int rows, int cols, int n
     if (int rc = run_timed_products(
             s, rows, iters, o, slots, [](double *) { return (int)SMVP_OK; },
             [A, &s](const double *x, double *yy, unsigned long long *stamps) { return csr_spmv_impl(A, x, yy, s.stream, stamps); }, rgrid,
-            [A, &s](const double *x, double *yy, unsigned long long *stamps, int reps, int grid, unsigned *ctl) {
-                return csr_spmv_repeat(A, x, yy, s.stream, stamps, reps, grid, ctl);
+            [A, &s](const double *x, double *yy, unsigned long long *stamps, int reps, int grid, unsigned *ctl, bool first, unsigned long long patience) {
+                return csr_spmv_repeat(A, x, yy, s.stream, stamps, reps, grid, ctl, first, patience);
             }))
         return rc;
     return finish_run(s, rows, iters, y, time_each_ms, stats);
@@ -2029,8 +2047,8 @@ extern "C" int smvp_tjds_compute(const smvp_coo_t *coo, int rows, int cols, int 
                 return tjds_spmv_impl(T, yy, s.stream, stamps);
             },
             slots > 0 ? csr_repeat_grid(T->rg) : 0,  // (tjds_can_stamp: the row-gather product, which overwrites y and needs no `pre`)
-            [T, &s](const double *, double *yy, unsigned long long *stamps, int reps, int grid, unsigned *ctl) {
-                return csr_spmv_repeat(T->rg, T->d_x_perm, yy, s.stream, stamps, reps, grid, ctl);
+            [T, &s](const double *, double *yy, unsigned long long *stamps, int reps, int grid, unsigned *ctl, bool first, unsigned long long patience) {
+                return csr_spmv_repeat(T->rg, T->d_x_perm, yy, s.stream, stamps, reps, grid, ctl, first, patience);
             }))
         return rc;
     return finish_run(s, rows, iters, y, time_each_ms, stats);

@@ -64,13 +64,18 @@ int owner_stamp_slots(int ntiles, int flavor);  // {first, last} tick pairs one 
 // the repeating form: `reps` products in one launch, every product's window stamped (csr_stream_owner_repeat).  grid =
 // owner_repeat_grid(...) workgroups (0: no such form for this plan / device), stamps = reps * grid * 4 {first, last} pairs in
 // l.stamps, ctl_words = kRepeatCtlWords unsigned of device memory; *top bit 31 set afterwards = the launch gave up (abort)
-constexpr int kRepeatCtlWords = 32 * 65;  // 32 shard counters, 32 go words, the top counter (bit 31: abort; the last line), each on a 128-byte line of its own
+constexpr int kRepeatCtlWords = 32 * 66;  // the run's sticky give-up word, 32 shard counters, 32 go words, the top counter (bit 31: abort; the last line), each on a 128-byte line of its own
+constexpr unsigned kRepeatPatienceDefaultUs = 50000;  // how long a workgroup waits at one barrier before the launch gives up
 int owner_repeat_grid(int vpt, int flavor, int ntiles);
 // (the CSR flavours' plain launches live in the second translation unit of smvp_kernels.hip, compiled -DSMVP_TU_ILP with the
 // max-ILP scheduling strategy -- see the Makefile; `extra` is the launcher's OwnerExtra)
 hipError_t launch_owner_csr_ilp(int vpt, int flavor, const OwnerLaunch &l, const void *extra, unsigned grid_x, int group, hipStream_t stream);
+// first_of_run: clears the sticky give-up word too (later launches of the run leave at once when it is set); patience_ticks: of the
+// 100 MHz wall clock (repeat_patience_ticks below)
 hipError_t launch_csr_stream_owner_repeat(int vpt, int flavor, const OwnerLaunch &l, int reps, int grid, unsigned *ctl_words,
-                                          hipStream_t stream);
+                                          bool first_of_run, unsigned long long patience_ticks, hipStream_t stream);
+// smvp_run_opts_t.repeat_patience_us -> ticks: 0 = the default, negative = no patience at all (every workgroup that has to wait gives up)
+inline unsigned long long repeat_patience_ticks(int us) { return us < 0 ? 0ull : 100ull * (unsigned)(us ? us : (int)kRepeatPatienceDefaultUs); }
 hipError_t launch_stamp_reduce(const unsigned long long *stamps, int slots_per_product, int products,
                                unsigned long long *first_last, hipStream_t stream);
 hipError_t launch_tjds_products(const int *start_pos, const double *val, const double *x_perm, double *prod,
@@ -192,8 +197,20 @@ __device__ __forceinline__ double dpp_row_shl(double v)
     return __hiloint2double(hi, lo);
 }
 
+//
+// ORDER (which forms sum a long row alike): this helper adds lanes i, i+8, i+4, i+2, i+1 inside each row of 16 lanes and then
+// (r0 + r1) + (r2 + r3) -- not the order of a __shfl_down tree over 64 lanes (32, 16, 8, 4, 2, 1).  It is what the tile kernel
+// (csr_stream_owner, CSR and TJDS flavours), the binned plan's pass B and the near-window kernel use for rows of more than 32
+// entries; csr_stream_tiles (STREAM_CARRY), csr_vector_rows and the tile kernel's giant-row path (rows beyond one tile) keep
+// shfl_down_sum<64>.  Rows of up to 32 entries are summed left to right by one lane in every form (the serial loop's bits);
+// longer rows agree between the two families within the row-normwise bound, not bit for bit.
+// Needs wave64 and a full EXEC mask: readlane of lanes 16 / 32 / 48 reads whatever an inactive lane holds -- call it from
+// wave-uniform control flow only (every caller loops over rows with a wave-uniform trip count).
 __device__ __forceinline__ double wave_sum_dpp(double v)
 {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "wave_sum_dpp: four DPP rows of 16 lanes = one wave64 (gfx9 / CDNA only)"
+#endif
     v += dpp_row_shl<8>(v);
     v += dpp_row_shl<4>(v);
     v += dpp_row_shl<2>(v);

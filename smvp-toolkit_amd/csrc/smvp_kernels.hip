@@ -229,25 +229,39 @@ typedef int int4v __attribute__((ext_vector_type(4)));               // clang ve
 // The streams every flavour reads are plain __restrict__ kernel parameters (the compiler then keeps the uniform plan
 // reads on the scalar unit and is free to order the loads); what only some flavours need travels in this struct.
 struct OwnerExtra {
-    const int *pos;                 // Tjds*: TJDS position of each stream entry
-    const int *start_pos;           // TjdsS
-    const int *ovf_ptr;             // TjdsS: ntiles + 1 bounds of the tiles' overflow entries in ovf_val / ovf_k
-    const double *ovf_val;          // TjdsS: value ...
-    const int *ovf_k;               // TjdsS: ... and permuted column of the entries [e, tile_next) of each tile, row order
-    const int *cache_ptr;           // TjdsS: ntiles + 1 bounds of the tiles' runs in val_cache (a tile's last entries)
-    const double *val_cache;        // TjdsS: values of the entries whose val lines scatter over many tiles, tile by tile
-    const unsigned short *col16;    // Csr16: column - col_base[tile] per entry
-    const int *col_base;            // Csr16: smallest column of every tile
-    const unsigned *word32;         // TjdsH, per entry: low 16 bits of its position (cached entries: of its permuted column) | (slot | run hint << kSlotBits) << 16
-    const unsigned short *group_run;  // TjdsH: per tile and group of 32 entries, the run (inside the tile) of its first entry
-    const int *run_ptr;             // TjdsH: ntiles + 1 bounds of the tiles' runs in run_tab
-    const int *run_tab;             // TjdsH: per run {base of its block of 2^16 positions, start_pos of its diagonal} (cached: {column block, 0})
-    int unit_x;                     // TjdsH: the operand is the unit vector -- no x gather; overflow entries are POSITIONS in ovf_k (their
+    const int *pos = nullptr;                 // Tjds*: TJDS position of each stream entry
+    const int *start_pos = nullptr;           // TjdsS
+    const int *ovf_ptr = nullptr;             // TjdsS: ntiles + 1 bounds of the tiles' overflow entries in ovf_val / ovf_k
+    const double *ovf_val = nullptr;          // TjdsS: value ...
+    const int *ovf_k = nullptr;               // TjdsS: ... and permuted column of the entries [e, tile_next) of each tile, row order
+    const int *cache_ptr = nullptr;           // TjdsS: ntiles + 1 bounds of the tiles' runs in val_cache (a tile's last entries)
+    const double *val_cache = nullptr;        // TjdsS: values of the entries whose val lines scatter over many tiles, tile by tile
+    const unsigned short *col16 = nullptr;    // Csr16: column - col_base[tile] per entry
+    const int *col_base = nullptr;            // Csr16: smallest column of every tile
+    const unsigned *word32 = nullptr;         // TjdsH, per entry: low 16 bits of its position (cached entries: of its permuted column) | (slot | run hint << kSlotBits) << 16
+    const unsigned short *group_run = nullptr;  // TjdsH: per tile and group of 32 entries, the run (inside the tile) of its first entry
+    const int *run_ptr = nullptr;             // TjdsH: ntiles + 1 bounds of the tiles' runs in run_tab
+    const int *run_tab = nullptr;             // TjdsH: per run {base of its block of 2^16 positions, start_pos of its diagonal} (cached: {column block, 0})
+    int unit_x = 0;                     // TjdsH: the operand is the unit vector -- no x gather; overflow entries are POSITIONS in ovf_k (their
                                     // values are read from val like everybody's: val changes from launch to launch, see the engine's TjdsSource)
-    const unsigned short *row_rel;  // every row's first entry relative to the first entry of the tile it
+    const unsigned short *row_rel = nullptr;  // every row's first entry relative to the first entry of the tile it
                                     // starts in (2 B per row read by the product instead of row_ptr's 4); nullptr: row_ptr itself
-    unsigned long long *stamps;     // STAMPED: per-wave {first, last} wall-clock ticks of this launch
+    unsigned long long *stamps = nullptr;     // STAMPED: per-wave {first, last} wall-clock ticks of this launch
 };
+
+// The ONE place an OwnerExtra is filled from a launch description (the plain launcher, the ILP unit's launcher through it, the
+// repeating launcher): a field added to either struct is carried -- or left at its null default -- here and nowhere else.
+[[maybe_unused]] static inline OwnerExtra owner_extra_of(const OwnerLaunch &l, unsigned long long *stamps)
+{
+    OwnerExtra ex{};
+    ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_val = l.ovf_val, ex.ovf_k = l.ovf_k;
+    ex.cache_ptr = l.cache_ptr, ex.val_cache = l.val_cache;
+    ex.col16 = l.col16, ex.col_base = l.col_base;
+    ex.unit_x = l.unit_x, ex.word32 = l.word32, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_tab = l.run_tab;
+    ex.row_rel = l.row_rel;
+    ex.stamps = stamps;
+    return ex;
+}
 
 // what the helpers below need of the kernel's arguments
 struct OwnerArgs {
@@ -289,7 +303,8 @@ __device__ __forceinline__ double owner_overflow_product(const OwnerArgs &a, int
 // Thread 0 of every workgroup adds the 100 MHz wall-clock ticks between its phase boundaries to six global counters;
 // smvp_debug_phase_stamps() (engine) prints and clears them.  The normal build contains none of this.
 #if defined(SMVP_PHASE_STAMPS) && defined(SMVP_TU_ILP)
-#undef SMVP_PHASE_STAMPS   // (the diagnostic build runs every flavour in the other unit)
+#undef SMVP_PHASE_STAMPS   // (the diagnostic build runs every flavour in the other unit ...
+#define SMVP_ILP_UNIT_UNUSED  // ... and this unit instantiates no owner kernel: one device body per kernel name in the library)
 #endif
 #ifdef SMVP_PHASE_STAMPS
 __device__ unsigned long long g_owner_phase[8];
@@ -769,20 +784,27 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner(
 // reduced by stamp_reduce -- windows that cannot overlap, one per product, inside one launch.
 //
 // The grid must be resident as a whole (the launcher sizes it from the occupancy query, with a margin); every poll is
-// bounded all the same: a workgroup that waits longer than kRepeatPatience wall-clock ticks sets the top counter's abort bit,
-// everybody leaves, and the host falls back to single launches.
+// bounded all the same: a workgroup that waits longer than the launch's patience (50 ms unless the caller says otherwise --
+// a product of a grid that is resident at once takes microseconds) sets the top counter's abort bit and the run's sticky
+// give-up word, everybody leaves, launches of the same run queued behind it leave as they start, and the host -- which waits
+// for the FIRST launch of a run before it queues the others -- falls back to single launches.
 // ---------------------------------------------------------------------------
 constexpr int kRepeatMaxShards = 32;
 constexpr unsigned kRepeatAbort = 0x80000000u;
-constexpr unsigned long long kRepeatPatience = 300ull * 1000 * 1000;  // 3 s of the 100 MHz wall clock
 
+// ctl_words (kRepeatCtlWords unsigned, every word on a 128-byte line of its own): line 0 the STICKY give-up word of a run -- set by the
+// launch that gives up, never cleared between the launches of one run, read by every workgroup of a later launch before it
+// does anything: launches already enqueued behind one that gave up leave at once instead of waiting out their own patience;
+// lines 1..32 the shard counters, 33..64 the go words, the last line the top counter (bit 31: this launch gave up).
 struct RepeatCtl {
-    unsigned *shard;           // `shards` counters, 32 words (128 B) apart
-    unsigned *top;             // one counter; bit 31 = abort
-    unsigned *go;              // `shards` generation words, 128 B apart: what the workgroups of a shard poll (sharded grids)
-    unsigned long long *stamps;  // reps * slots_per_product * 2
-    int reps, grid_virtual, slots_per_product;
-    int shards;                // 1: every workgroup counts on `top` itself (small grids); else about sqrt(workgroups), a power of two
+    unsigned *sticky = nullptr;  // the run's give-up word (see above)
+    unsigned *shard = nullptr;   // `shards` counters, 32 words (128 B) apart
+    unsigned *top = nullptr;     // one counter; bit 31 = abort
+    unsigned *go = nullptr;      // `shards` generation words, 128 B apart: what the workgroups of a shard poll (sharded grids)
+    unsigned long long *stamps = nullptr;  // reps * slots_per_product * 2
+    int reps = 0, grid_virtual = 0, slots_per_product = 0;
+    int shards = 1;              // 1: every workgroup counts on `top` itself (small grids); else about sqrt(workgroups), a power of two
+    unsigned long long patience = 0;  // ticks of the 100 MHz wall clock a workgroup waits at one barrier before the launch gives up
 };
 
 template <int VPT, int FLAVOR>
@@ -799,6 +821,15 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner_repeat(
     const unsigned members = (nwg - sh + S - 1) / S;   // workgroups of this shard
     const unsigned arrivals = S > 1 ? (nwg < S ? nwg : S) : nwg;  // what `top` counts per product: shards with members, or workgroups
     unsigned long long *stamp = ctl.stamps + 2 * ((size_t)me * (kStreamBlock / 64) + (t >> 6));
+    // an earlier launch of this run gave up: so does this one, at once (and says so on its own top word, which the host reads)
+    if (t == 0) {
+        go = __hip_atomic_load(ctl.sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0u : 1u;
+        if (!go)
+            atomicOr(ctl.top, kRepeatAbort);
+    }
+    __syncthreads();
+    if (!go)
+        return;
     for (int rep = 0; rep < ctl.reps; ++rep) {
         // ---- every workgroup has finished product rep - 1 (its stores acknowledged) before anybody starts product rep
         __syncthreads();
@@ -816,9 +847,11 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner_repeat(
                 const unsigned before = atomicAdd(ctl.shard + 32 * sh, 1u);
                 if (before + 1u == members * gen) {
                     const unsigned tb = atomicAdd(ctl.top, 1u);
+                    // (a maximum, not a store: a go word that already says kRepeatAbort -- the largest unsigned in play --
+                    // keeps saying it, whoever arrives last)
                     if ((tb & ~kRepeatAbort) + 1u == arrivals * gen)
                         for (unsigned q = 0; q < S; ++q)
-                            __hip_atomic_store(ctl.go + 32 * q, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_max(ctl.go + 32 * q, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 for (;;) {
                     const unsigned g = __hip_atomic_load(ctl.go + 32 * sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -828,10 +861,11 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner_repeat(
                         seen = kRepeatAbort;
                         break;
                     }
-                    if (wall_clock64() - t0 > kRepeatPatience) {
+                    if (wall_clock64() - t0 > ctl.patience) {
                         atomicOr(ctl.top, kRepeatAbort);
+                        __hip_atomic_store(ctl.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         for (unsigned q = 0; q < S; ++q)
-                            __hip_atomic_store(ctl.go + 32 * q, kRepeatAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_max(ctl.go + 32 * q, kRepeatAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         seen = kRepeatAbort;
                         break;
                     }
@@ -843,8 +877,9 @@ __global__ __launch_bounds__(kStreamBlock) void csr_stream_owner_repeat(
                     seen = __hip_atomic_load(ctl.top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if ((seen & kRepeatAbort) || (seen & ~kRepeatAbort) >= arrivals * gen)
                         break;
-                    if (wall_clock64() - t0 > kRepeatPatience) {
+                    if (wall_clock64() - t0 > ctl.patience) {
                         atomicOr(ctl.top, kRepeatAbort);
+                        __hip_atomic_store(ctl.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         seen = kRepeatAbort;
                         break;
                     }
@@ -1149,13 +1184,7 @@ hipError_t launch_csr_stream_owner(int vpt, int flavor, const OwnerLaunch &l, hi
         return hipSuccess;
     const int group = tile_group(l.ntiles, flavor_group(flavor));
     const dim3 grid(owner_grid(l.ntiles, group));
-    OwnerExtra ex;
-    ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_val = l.ovf_val, ex.ovf_k = l.ovf_k;
-    ex.cache_ptr = l.cache_ptr, ex.val_cache = l.val_cache;
-    ex.col16 = l.col16, ex.col_base = l.col_base;
-    ex.unit_x = l.unit_x, ex.word32 = l.word32, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_tab = l.run_tab;
-    ex.stamps = l.stamps;
-    ex.row_rel = l.row_rel;
+    const OwnerExtra ex = owner_extra_of(l, l.stamps);
 #define SMVP_OWNER_ST(V, F, S)                                                                                     \
     hipLaunchKernelGGL((csr_stream_owner<V, F, S>), grid, dim3(kStreamBlock), 0, stream, l.row_ptr, l.col_ind, l.val, \
                        l.x, l.y, l.tile_row, l.tile_next, l.rows, l.nnz, l.ntiles, group, ex)
@@ -1232,32 +1261,32 @@ int owner_repeat_grid(int vpt, int flavor, int ntiles)
     return full <= cap ? full : 0;
 }
 
-// `reps` products, each stamped: stamps[reps][grid * 4][2]; ctl_words: kRepeatCtlWords unsigned, cleared here.
+// `reps` products, each stamped: stamps[reps][grid * 4][2]; ctl_words: kRepeatCtlWords unsigned -- the counters are cleared here
+// for every launch, the sticky give-up word only for the first launch of a run.  Refuses (hipErrorInvalidValue, nothing is
+// launched) a launch whose control block would be incomplete: no stamps, no control words, no products, no tiles to walk.
 hipError_t launch_csr_stream_owner_repeat(int vpt, int flavor, const OwnerLaunch &l, int reps, int grid, unsigned *ctl_words,
-                                          hipStream_t stream)
+                                          bool first_of_run, unsigned long long patience_ticks, hipStream_t stream)
 {
-    if (l.rows <= 0 || reps <= 0)
+    if (l.rows <= 0)
         return hipSuccess;
-    if (grid <= 0 || !l.stamps || !ctl_words)
-        return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(ctl_words, 0, sizeof(unsigned) * kRepeatCtlWords, stream);
-    if (e != hipSuccess)
-        return e;
     const int group = tile_group(l.ntiles, flavor_group(flavor));
-    OwnerExtra ex;
-    ex.pos = l.pos, ex.start_pos = l.start_pos, ex.ovf_ptr = l.ovf_ptr, ex.ovf_val = l.ovf_val, ex.ovf_k = l.ovf_k;
-    ex.cache_ptr = l.cache_ptr, ex.val_cache = l.val_cache;
-    ex.col16 = l.col16, ex.col_base = l.col_base;
-    ex.unit_x = l.unit_x, ex.word32 = l.word32, ex.group_run = l.group_run, ex.run_ptr = l.run_ptr, ex.run_tab = l.run_tab;
-    ex.stamps = nullptr;
-    ex.row_rel = l.row_rel;
-    RepeatCtl ctl;
-    ctl.shard = ctl_words, ctl.go = ctl_words + 32 * kRepeatMaxShards, ctl.top = ctl_words + kRepeatCtlWords - 32;
+    RepeatCtl ctl{};
+    ctl.sticky = ctl_words;
+    ctl.shard = ctl_words + 32, ctl.go = ctl_words + 32 * (1 + kRepeatMaxShards), ctl.top = ctl_words + kRepeatCtlWords - 32;
     // arrivals cost about 12 ns each on one address: n / S on a shard, then S on the top counter
     // measured (profiles/r05_cli_n1000.txt): one level up to two dozen workgroups, 8 shards up to ~600, 16 beyond
     ctl.shards = grid <= 24 ? 1 : grid <= 640 ? 8 : 16;
     ctl.stamps = l.stamps;
     ctl.reps = reps, ctl.grid_virtual = (int)owner_grid(l.ntiles, group), ctl.slots_per_product = grid * (kStreamBlock / 64);
+    ctl.patience = patience_ticks;
+    if (reps <= 0 || grid <= 0 || ctl.grid_virtual <= 0 || !ctl.stamps || !ctl_words)
+        return hipErrorInvalidValue;
+    static_assert(kRepeatCtlWords == 32 * (2 + 2 * kRepeatMaxShards), "sticky + shards + go words + top, one 128-byte line each");
+    hipError_t e = first_of_run ? hipMemsetAsync(ctl_words, 0, sizeof(unsigned) * kRepeatCtlWords, stream)
+                                : hipMemsetAsync(ctl_words + 32, 0, sizeof(unsigned) * (kRepeatCtlWords - 32), stream);
+    if (e != hipSuccess)
+        return e;
+    const OwnerExtra ex = owner_extra_of(l, nullptr);
 #define X(V, F)                                                                                                                    \
     if (vpt == V && flavor == F) {                                                                                                 \
         hipLaunchKernelGGL((csr_stream_owner_repeat<V, F>), dim3((unsigned)grid), dim3(kStreamBlock), 0, stream, l.row_ptr, l.col_ind, \
@@ -1359,6 +1388,9 @@ hipError_t launch_fill(double *p, double v, long long n, hipStream_t stream)
 }
 
 #else  // SMVP_TU_ILP: the plain launches of the CSR flavours (launch_csr_stream_owner in the other unit prepares `extra`, grid and group)
+#ifdef SMVP_ILP_UNIT_UNUSED   // a -DSMVP_PHASE_STAMPS diagnostic build: every flavour is launched from the other unit, nothing is instantiated here
+hipError_t launch_owner_csr_ilp(int, int, const OwnerLaunch &, const void *, unsigned, int, hipStream_t) { return hipErrorInvalidValue; }
+#else
 hipError_t launch_owner_csr_ilp(int vpt, int flavor, const OwnerLaunch &l, const void *extra, unsigned grid_x, int group, hipStream_t stream)
 {
     const OwnerExtra &ex = *static_cast<const OwnerExtra *>(extra);
@@ -1383,6 +1415,7 @@ hipError_t launch_owner_csr_ilp(int vpt, int flavor, const OwnerLaunch &l, const
 #undef SMVP_OWNER_ST
     return hipErrorInvalidValue;
 }
+#endif  // SMVP_ILP_UNIT_UNUSED
 #endif  // SMVP_TU_ILP
 
 }  // namespace smvp

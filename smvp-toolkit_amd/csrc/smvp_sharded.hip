@@ -194,6 +194,7 @@ struct smvp_sharded {
     bool auto_exchange = false;         // created with AUTO: a probe keeps the fastest form
     bool have_rccl = false, have_peer = false;  // what can be selected
     double probe_ms[3] = {-1.0, -1.0, -1.0};    // last probe: one product's exchange by form
+    bool form_off[3] = {false, false, false};   // a form that failed in a probe is not offered again
     std::string rccl_why;                       // why RCCL is not available (AUTO)
     PushTargets targets;                        // DIRECT: every rank's full vector
     std::vector<hipEvent_t> ev_pushed, ev_placed;
@@ -812,7 +813,48 @@ int run_job(smvp_sharded *h, int allgather, int timed, bool skip_products)
 
 bool exchange_available(const smvp_sharded *h, int e)
 {
-    return e == SMVP_EXCHANGE_RCCL ? h->have_rccl : (e == SMVP_EXCHANGE_COPIES || e == SMVP_EXCHANGE_DIRECT) ? h->have_peer : false;
+    if (e < SMVP_EXCHANGE_RCCL || e > SMVP_EXCHANGE_DIRECT || h->form_off[e])
+        return false;
+    return e == SMVP_EXCHANGE_RCCL ? h->have_rccl : h->have_peer;
+}
+
+// A form failed while it was being probed (nothing but the probe's own exchanges was in flight): it is taken out of the
+// offer and the handle made usable again, so that the probe can go on with the forms that are left.  RCCL: its communicators
+// are aborted -- a collective some rank never joined would otherwise keep that rank's stream busy for ever -- which needs
+// ncclCommAbort; without it the failure stands.  Returns whether the handle is usable again.
+bool retire_form(smvp_sharded *h, int e)
+{
+    if (e == SMVP_EXCHANGE_RCCL) {
+        if (!h->rccl || !h->rccl->CommAbort)
+            return false;
+        DeviceScope keep;
+        for (size_t i = 0; i < h->comm.size(); ++i)
+            if (h->comm[i]) {
+                (void)hipSetDevice(h->device[i]);
+                h->rccl->CommAbort(h->comm[i]);
+                h->comm[i] = nullptr;
+            }
+        h->have_rccl = false;
+        h->rccl_why = "failed in the exchange probe: " + std::string(smvp_last_error());
+    }
+    h->form_off[e] = true;
+    {
+        DeviceScope keep;
+        for (size_t i = 0; i < h->device.size(); ++i) {  // whatever the failed exchange left on the devices has to be over
+            if (hipSetDevice(h->device[i]) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lock(h->phase_mu);
+        h->phase_abort = false;
+        h->phase_waiting = 0;
+    }
+    h->broken = false;
+    h->broken_why.clear();
+    return true;
 }
 
 }  // namespace
@@ -844,23 +886,39 @@ extern "C" int smvp_sharded_probe_exchange(smvp_sharded_t *h, int reps)
             continue;
         h->exchange = e;
         double sum = 0.0;
+        bool failed = false;
         for (int i = 0; i <= reps; ++i) {
             int rc = run_job(h, SMVP_GATHER_AFTER, 1, true);
             double ms = 0.0;
             if (rc == SMVP_OK)
                 rc = smvp_sharded_synchronize(h, &ms);
             if (rc != SMVP_OK) {
-                h->exchange = before;
-                return rc;
+                // this form does not work here: go on with the others if the handle can be made usable again, fail only when
+                // none is left (one failing form used to fail the whole create under AUTO)
+                failed = true;
+                if (!retire_form(h, e)) {
+                    h->exchange = before;
+                    return rc;
+                }
+                break;
             }
             if (i > 0)
                 sum += ms;
         }
+        if (failed)
+            continue;
         h->probe_ms[e] = sum / reps;
         if (best < 0 || h->probe_ms[e] < h->probe_ms[best])
             best = e;
     }
-    h->exchange = h->auto_exchange && best >= 0 ? best : before;
+    if (best < 0)
+        return smvp::fail(SMVP_ERR_HIP, "no exchange form survived the probe (last: %s)", smvp_last_error());
+    // AUTO leaves its starting form (RCCL where there is one, else the push kernel) only for a form that is more than 5 %
+    // faster: three timed exchanges of a few tens of microseconds differ by that much from run to run
+    int keep = exchange_available(h, before) ? before : best;
+    if (h->auto_exchange && best != keep && !(h->probe_ms[best] < 0.95 * h->probe_ms[keep]))
+        best = keep;
+    h->exchange = h->auto_exchange ? best : keep;
     return SMVP_OK;
 }
 
@@ -871,8 +929,9 @@ extern "C" int smvp_sharded_exchange_info(const smvp_sharded_t *h, int *active, 
     if (active)
         *active = h->exchange;
     if (available)
-        *available = (h->have_rccl ? 1 << SMVP_EXCHANGE_RCCL : 0) |
-                     (h->have_peer ? (1 << SMVP_EXCHANGE_COPIES) | (1 << SMVP_EXCHANGE_DIRECT) : 0);
+        *available = (exchange_available(h, SMVP_EXCHANGE_RCCL) ? 1 << SMVP_EXCHANGE_RCCL : 0) |
+                     (exchange_available(h, SMVP_EXCHANGE_COPIES) ? 1 << SMVP_EXCHANGE_COPIES : 0) |
+                     (exchange_available(h, SMVP_EXCHANGE_DIRECT) ? 1 << SMVP_EXCHANGE_DIRECT : 0);
     if (ms)
         for (int e = 0; e < 3; ++e)
             ms[e] = h->probe_ms[e];

@@ -37,7 +37,7 @@ class RunOpts(C.Structure):
     _fields_ = [("struct_size", C.c_uint), ("device", C.c_int), ("csr_kernel", C.c_int), ("csr_param", C.c_int),
                 ("tjds_ref_quirks", C.c_int), ("convert_on_device", C.c_int), ("ngpus", C.c_int),
                 ("iterate", C.c_int), ("normalize", C.c_int), ("tjds_mode", C.c_int), ("timing", C.c_int),
-                ("shard_exchange", C.c_int), ("x", C.c_void_p)]
+                ("shard_exchange", C.c_int), ("repeat_patience_us", C.c_int), ("x", C.c_void_p)]
 
 
 class PlanInfo(C.Structure):
@@ -46,7 +46,7 @@ class PlanInfo(C.Structure):
 
 class RunInfo(C.Structure):
     _fields_ = [("timing", C.c_int), ("graph_replays", C.c_int), ("wall_ms", C.c_double), ("device_clock_khz", C.c_double),
-                ("repeat_launches", C.c_int), ("reserved", C.c_int)]
+                ("repeat_launches", C.c_int), ("repeat_gave_up", C.c_int)]
 
 
 class ShardOpts(C.Structure):
@@ -639,13 +639,14 @@ class ShardedMatrix:
 
 # ------------------------------------------------- reference-shaped entry points
 def _run_opts(device, csr_kernel, csr_param, ref_quirks, x, device_convert=False, ngpus=0, iterate=False,
-              normalize=False, tjds_mode=TJDS_MODE_AUTO, timing=TIMING_AUTO, exchange=EXCHANGE_AUTO):
+              normalize=False, tjds_mode=TJDS_MODE_AUTO, timing=TIMING_AUTO, exchange=EXCHANGE_AUTO, repeat_patience_us=0):
     o = RunOpts()
     lib().smvp_run_opts_default(C.byref(o))
     o.device, o.csr_kernel, o.csr_param, o.tjds_ref_quirks = device, csr_kernel, csr_param, int(ref_quirks)
     o.convert_on_device, o.ngpus = int(device_convert), int(ngpus)
     o.iterate, o.normalize = int(iterate), int(normalize)
     o.tjds_mode, o.timing, o.shard_exchange = int(tjds_mode), int(timing), int(exchange)
+    o.repeat_patience_us = int(repeat_patience_us)
     keep = None
     if x is not None:
         keep = _arr(x, np.float64)
@@ -661,21 +662,22 @@ def last_run_info():
 
 
 def csr_compute(coo, rows, cols, iters=1, device=0, kernel=CSR_KERNEL_AUTO, param=0, x=None, device_convert=False,
-                ngpus=0, iterate=False, normalize=False, timing=TIMING_AUTO, exchange=EXCHANGE_AUTO):
+                ngpus=0, iterate=False, normalize=False, timing=TIMING_AUTO, exchange=EXCHANGE_AUTO, repeat_patience_us=0):
     """smvp_csr_compute: COO in, (y, per-iteration ms, TimeStats) out."""
     nnz = len(coo)
     coo = _arr(coo, COO_DTYPE)
     y = np.zeros(max(rows, 1), dtype=np.float64)
     ms = np.zeros(iters, dtype=np.float64)
     st = TimeStats()
-    o, keep = _run_opts(device, kernel, param, False, x, device_convert, ngpus, iterate, normalize, timing=timing, exchange=exchange)
+    o, keep = _run_opts(device, kernel, param, False, x, device_convert, ngpus, iterate, normalize, timing=timing, exchange=exchange,
+                        repeat_patience_us=repeat_patience_us)
     _check(lib().smvp_csr_compute(_p(coo), rows, cols, nnz, iters, C.byref(o), _p(y), _p(ms), C.byref(st)),
            "smvp_csr_compute")
     return y[:rows], ms, st
 
 
 def tjds_compute(coo, rows, cols, iters=1, device=0, ref_quirks=False, x=None, device_convert=False, ngpus=0,
-                 iterate=False, normalize=False, mode=TJDS_MODE_AUTO, timing=TIMING_AUTO, exchange=EXCHANGE_AUTO):
+                 iterate=False, normalize=False, mode=TJDS_MODE_AUTO, timing=TIMING_AUTO, exchange=EXCHANGE_AUTO, repeat_patience_us=0):
     """smvp_tjds_compute: COO in, (y, per-iteration ms, TimeStats) out."""
     nnz = len(coo)
     coo = _arr(coo, COO_DTYPE)
@@ -683,7 +685,7 @@ def tjds_compute(coo, rows, cols, iters=1, device=0, ref_quirks=False, x=None, d
     ms = np.zeros(iters, dtype=np.float64)
     st = TimeStats()
     o, keep = _run_opts(device, CSR_KERNEL_AUTO, 0, ref_quirks, x, device_convert, ngpus, iterate, normalize,
-                        tjds_mode=mode, timing=timing, exchange=exchange)
+                        tjds_mode=mode, timing=timing, exchange=exchange, repeat_patience_us=repeat_patience_us)
     _check(lib().smvp_tjds_compute(_p(coo), rows, cols, nnz, iters, C.byref(o), _p(y), _p(ms), C.byref(st)),
            "smvp_tjds_compute")
     return y[:rows], ms, st

@@ -9,6 +9,8 @@ import smvp_toolkit_amd as sm
 from smvp_toolkit_amd import sharding
 
 import bench
+import bench_core
+import bench_legs
 
 
 def args_for(**kw):
@@ -22,10 +24,10 @@ def args_for(**kw):
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_blocks_tile_the_whole(workload, world):
     a = args_for()
-    whole = bench.build_block(sm, sharding, workload, a, 0, 1)
+    whole = bench_core.build_block(sm, sharding, workload, a, 0, 1)
     rows_seen, parts = 0, []
     for rank in range(world):
-        blk = bench.build_block(sm, sharding, workload, a, rank, world)
+        blk = bench_core.build_block(sm, sharding, workload, a, rank, world)
         assert blk["rows_total"] == whole["rows_total"] and blk["cols_total"] == whole["cols_total"]
         assert blk["r0"] == rows_seen and blk["r1"] - blk["r0"] == blk["rows"] == len(blk["row_ptr"]) - 1
         assert blk["bounds"][rank] == blk["r0"] and blk["bounds"][rank + 1] == blk["r1"]
@@ -42,7 +44,7 @@ def test_blocks_tile_the_whole(workload, world):
 
 def test_tiled_block_is_kron_identity_memplus():
     a = args_for(copies=3)
-    blk = bench.build_block(sm, sharding, "memplus_tiled", a, 0, 1)
+    blk = bench_core.build_block(sm, sharding, "memplus_tiled", a, 0, 1)
     m, n, rp, ci, v, ncopies, report = blk["base"]
     assert ncopies == 3 and blk["rows"] == 3 * m and blk["nnz"] == 3 * len(ci)
     for c in range(3):
@@ -54,14 +56,14 @@ def test_tiled_block_is_kron_identity_memplus():
 
 def test_host_check_catches_a_wrong_row():
     a = args_for(copies=2)
-    blk = bench.build_block(sm, sharding, "memplus_tiled", a, 0, 1)
+    blk = bench_core.build_block(sm, sharding, "memplus_tiled", a, 0, 1)
     x = np.ones(blk["cols_total"])
     good = np.add.reduceat(blk["val"], blk["row_ptr"][:-1])
-    ok, worst, scale = bench.host_check(blk, x, good)
+    ok, worst, scale = bench_core.host_check(blk, x, good)
     assert ok and worst < 1e-12
     bad = good.copy()
     bad[123] += 1e-6 * scale[123]
-    assert not bench.host_check(blk, x, bad)[0]
+    assert not bench_core.host_check(blk, x, bad)[0]
 
 
 def test_c_layer_child_is_given_up_on_when_it_hangs(tmp_path, monkeypatch):
@@ -73,8 +75,8 @@ def test_c_layer_child_is_given_up_on_when_it_hangs(tmp_path, monkeypatch):
     def child(body):
         f = tmp_path / "child.py"
         f.write_text(body)
-        monkeypatch.setattr(bench.os.path, "abspath", lambda p: str(f) if str(p).endswith("bench.py") else p)
-        return bench.c_layer_in_child(argparse.Namespace(rows=1000, c_layer_budget=1.5), 8, 5, rank=1)
+        monkeypatch.setattr(bench_core, "BENCH_SCRIPT", str(f))
+        return bench_legs.c_layer_in_child(argparse.Namespace(rows=1000, c_layer_budget=1.5), 8, 5, rank=1)
 
     t0 = time.time()
     out = child("import time\ntime.sleep(60)\n")
@@ -144,7 +146,7 @@ def test_self_launched_ranks_really_run(tmp_path):
 
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     t0 = time.time()
-    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(bench.__file__), "bench.py"), "--gpus", "2", "--no-c-layer",
+    p = subprocess.run([sys.executable, bench_core.BENCH_SCRIPT, "--gpus", "2", "--no-c-layer",
                         "--no-config4", "--copies", "2", "--steps", "1"], capture_output=True, text=True, env=env, timeout=300)
     try:
         import torch
@@ -169,10 +171,85 @@ def test_flat_keys_are_scalars_and_complete():
                                   "exchange_rccl_ms": 0.1, "exchange_direct_ms": 0.05, "exchange_chosen": "direct", "rccl_ranks": 8},
               "sample_matrices_us_per_product": {"memplus.mtx": {"csr_avg_ms": 3.1, "tjds_loop_wall_ms_per_product": 6.0}, "note": "x"}}
     extra = {"tjds_two_phase": {"frac_of_hbm_peak": 0.25}, "config5_pwt": {"csr_ms_per_step": 0.0037}}
-    bench.flat_keys(roof, others, extra, 8, {"backend": "nccl (RCCL)", "rccl_ranks": 8, "exchange": "e" * 300, "self_launched": True})
+    bench_legs.flat_keys(roof, others, extra, 8, {"backend": "nccl (RCCL)", "rccl_ranks": 8, "exchange": "e" * 300, "self_launched": True})
     assert all(not isinstance(v, (dict, list)) for v in roof.values())
     assert roof["frac_tjds"] == 0.5 and roof["traffic_over_alg_tjds"] == 1.44 and roof["frac_tjds_colmajor"] == 0.25
     assert roof["config4_speedup_overlapped"] == 3.6 and roof["config4_chunks_chosen"] == 2 and roof["config4_eighth_ms_1chunk"] == 0.41
     assert roof["config4_c_layer_overlapped_ms_1chunk"] == 2.3 and roof["exchange_direct_ms"] == 0.05 and roof["c_layer_rccl_ranks"] == 8
     assert roof["config4_c_layer_step_best_ms"] == 2.3 and roof["config4_c_layer_speedup_best"] == round(2.2 / 2.3, 3)
     assert roof["memplus_csr_us"] == 3.1 and roof["config5_csr_us"] == 3.7 and roof["rccl_ranks"] == 8 and roof["n_gpus"] == 8
+
+
+def _state(**roofline_more):
+    import time
+
+    roof = {"bound": "hbm", "kernel": "csr_stream_owner<8, 5, false>", "achieved": 6230.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.7787,
+            "traffic": 1601886515.1999998, "alg_bytes_per_launch": 1764298244.0, "ms_per_launch": 0.28319, "launches_per_product": 1,
+            "ms_per_product": 0.28319, "plan": {"plan_bytes": 1}, "others": {"tjds": {"frac": 0.6}}, "note": "n" * 500}
+    roof.update(roofline_more)
+    return {"t0": time.time(), "errors": {}, "leg_seconds": {"headline": 12.3, "tjds": 4.0}, "extra": {"dist": {}}, "others": {"tjds": {"frac": 0.6}},
+            "cpu": {"value": 0.9, "unit": "GFLOP/s", "cores": 1, "kind": "port", "host_cpu": "AMD EPYC", "sample": "s" * 400},
+            "head": {"metric": "fp64 CSR SpMV GFLOP/s", "value": 850.0, "unit": "GFLOP/s", "n_gpus": 8}, "config": {"workload": "w" * 400, "rows": 1},
+            "roofline": roof, "detail_path": "/nonexistent/bench_detail.json", "out": sys.stdout}
+
+
+def test_compact_line_is_short_flat_and_keeps_the_contract():
+    """The ONE stdout line: nothing nested below roofline / cpu_baseline / config, long strings cut, far below 8000 characters
+    whatever the legs put into `roofline`; what has to go goes in DROP_ORDER, the contract's own keys never."""
+    import json
+
+    flat = {"frac_tjds": 0.61, "frac_survey_random_model": 0.33, "frac_config4": 0.26, "config4_t1_ms": 1.96, "config4_speedup_overlapped": 5.5,
+            "rccl_ranks": 8}
+    text = bench.compact_line(_state(**flat))
+    j = json.loads(text)
+    assert len(text) < 3000 and "\n" not in text
+    for obj in (j["roofline"], j["cpu_baseline"], j["config"]):
+        assert all(not isinstance(v, (dict, list)) for v in obj.values())
+        assert all(len(v) <= bench.STRING_LIMIT for v in obj.values() if isinstance(v, str))
+    assert j["roofline"]["frac"] == 0.7787 and j["roofline"]["traffic"] == 1601890000.0 and j["cpu_baseline"]["cores"] == 1
+    assert all(j["roofline"][k] == v for k, v in flat.items()) and "dropped_for_length" not in j["roofline"]
+    assert j["roofline"]["leg_seconds"] == "headline 12, tjds 4" and j["value"] == 850.0 and j["n_gpus"] == 8
+    # far too many keys: the least important prefixes leave, the line fits, the contract's keys and the fractions stay
+    many = dict(flat, **{"memplus_k%d" % i: 0.123456 for i in range(300)}, **{"config4_c_layer_overlapped_ms_%d" % i: 1.5 for i in range(200)})
+    st = _state(**many)
+    st["errors"]["config4_c_layer"] = "timeout " * 100
+    text = bench.compact_line(st)
+    j = json.loads(text)
+    assert len(text) <= bench.LINE_LIMIT < 8000 and j["roofline"]["dropped_for_length"] is True
+    assert all(j["roofline"][k] == v for k, v in flat.items()) and j["roofline"]["ms_per_launch"] == 0.28319
+    assert j["roofline"]["config4_c_layer_error"].startswith("timeout") and len(j["roofline"]["config4_c_layer_error"]) <= bench.STRING_LIMIT
+
+
+def test_watchdog_prints_the_line_when_a_leg_hangs(tmp_path):
+    """A leg that never returns costs that leg: at the hard deadline the watchdog prints the compact line from what has been
+    measured (exit 0); with nothing measured yet it exits 3 and prints no line."""
+    import json
+    import subprocess
+    import textwrap
+
+    body = textwrap.dedent("""
+        import sys, time
+        sys.argv = ["bench.py"]
+        sys.path.insert(0, %r)
+        import bench
+        from test_bench_blocks import _state
+        st = _state(frac_tjds=0.61) if %s else {"t0": time.time(), "errors": {}, "leg_seconds": {}, "detail_path": %r, "out": sys.stdout}
+        st["detail_path"], st["leg"] = %r, "config4"
+        bench.Emitter(st, 0, 1.0)
+        time.sleep(60)
+    """)
+    import os
+    root = os.path.dirname(bench_core.BENCH_SCRIPT)
+    for measured in (True, False):
+        f = tmp_path / ("hang_%s.py" % measured)
+        detail = str(tmp_path / "detail.json")
+        f.write_text(body % (root, measured, detail, detail))
+        p = subprocess.run([sys.executable, str(f)], capture_output=True, text=True, timeout=60,
+                           env=dict(os.environ, PYTHONPATH=os.pathsep.join([root, os.path.join(root, "tests"), os.path.join(root, "smvp-toolkit_amd", "python")])))
+        if measured:
+            assert p.returncode == 0, p.stderr
+            j = json.loads(p.stdout.splitlines()[-1])
+            assert "config4" in j["roofline"]["watchdog"] and j["roofline"]["config4_error"] and j["roofline"]["frac_tjds"] == 0.61
+            assert j["detail"] == "detail.json" and json.load(open(detail))["roofline"]["plan"] == {"plan_bytes": 1}
+        else:
+            assert p.returncode == 3 and p.stdout == ""

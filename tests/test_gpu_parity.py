@@ -1237,58 +1237,43 @@ def test_uniform32_config4_shape(torch):
     A.close()
 
 
-def test_bench_script_runs_small(torch):
-    """bench.py end to end at toy size: one JSON line with the contract's keys, roofline and cpu_baseline."""
+def _bench(tmp_path, argv, env=None, timeout=900):
+    """bench.py as the driver runs it -> (the parsed LAST stdout line, its text, bench_detail.json)."""
     import json
     import sys
 
     from conftest import ROOT
 
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--copies", "8", "--rows-log2", "16", "--rows", "300000",
-                        "--steps", "5", "--warmup", "2", "--cpu-iters", "2", "--no-live-traffic"], capture_output=True, text=True)
-    assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    j = json.loads(lines[0])
+    detail = str(tmp_path / "bench_detail.json")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv + ["--detail", detail], capture_output=True, text=True, env=env,
+                       timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = p.stdout.splitlines()
+    assert len(out) == 1 and out[0].startswith("{")      # ONE line and nothing else on stdout (library banners go to stderr)
+    j = json.loads(out[-1])
+    assert len(out[-1]) < 8000, len(out[-1])
+    for obj in (j["roofline"], j["config"], j["cpu_baseline"] or {}):         # flat: nothing nested for a parser to drop
+        assert all(not isinstance(v, (dict, list)) for v in obj.values())
+    assert not [k for k in j["roofline"] if k.endswith("_error")], {k: v for k, v in j["roofline"].items() if k.endswith("_error")}
+    assert "watchdog" not in j["roofline"] and "dropped_for_length" not in j["roofline"]
+    return j, out[-1], json.load(open(detail))
+
+
+def test_bench_script_runs_small(torch, tmp_path):
+    """bench.py end to end at toy size: ONE compact JSON line (< 8000 characters, the last line of stdout) with the contract's keys,
+    `roofline` and `cpu_baseline` as flat scalars; everything else in bench_detail.json."""
+    j, text, d = _bench(tmp_path, ["--copies", "8", "--rows-log2", "16", "--rows", "300000", "--steps", "5", "--warmup", "2", "--cpu-iters", "2",
+                                   "--no-live-traffic"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in j
-    assert j["n_gpus"] == 1 and j["steps"] == 5 and j["dtype"] == "f64" and j["value"] > 0
-    assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
-    assert j["cpu_baseline"]["cores"] == 1 and j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["agrees_with_gpu"]
-    assert j["extra"]["full_size_parity"]["y_equals_tiled_reference_memplus_y"]
-    assert j["cpu_baseline"]["gpu_rows_bit_identical_to_serial"] > 0.98
-    assert "error" not in j["extra"]["tjds"] and "error" not in j["extra"]["survey_random_model"]
+    assert j["n_gpus"] == 1 and j["steps"] == 5 and j["dtype"] == "f64" and j["value"] > 0 and j["detail"] == "bench_detail.json"
+    r, cpu = j["roofline"], j["cpu_baseline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert cpu["cores"] == 1 and cpu["kind"] == "port" and cpu["agrees_with_gpu"] and cpu["value"] > 0 and cpu["host_cpu"]
+    assert cpu["gpu_rows_bit_identical_to_serial"] > 0.98 and r["y_equals_tiled_reference_y"] is True
     assert "substitute" in j["config"]["workload"]
-    c4, pw = j["extra"]["config4"], j["extra"]["pwt_tiled"]
-    assert "error" not in c4 and c4["n_gpus"] == 1 and c4["rows"] == 300000 and c4["nnz"] == 32 * 300000 and c4["spmv_only_ms"] > 0
-    assert "error" not in pw and pw["y_equals_tiled_reference_pwt_y"] and pw["tjds"]["equals_csr_bit_for_bit"]
-    c5 = j["extra"]["config5_pwt"]
-    assert "error" not in c5 and c5["y_equals_reference_report"] and 0 < c5["csr_ms_per_step"] < c5["csr_then_tjds_ms_per_step"]
-    sm_ = j["extra"]["sample_matrices"]["memplus.mtx"]
-    assert sm_["csr_avg_ms"] < sm_["csr_avg_ms_event_pairs"] and sm_["csr_agrees_with_cpu"] and sm_["tjds_agrees_with_cpu"]
-    # what the driver keeps: every other kernel priced inside `roofline`, and the C ABI's own sharded product timed
-    o = j["roofline"]["others"]
-    for key in ("tjds", "config4", "config4_c_layer", "pwt_tiled_csr", "pwt_tiled_tjds", "survey_random_model",
-                "sample_matrices_us_per_product"):
-        assert key in o and "error" not in o[key], key
-    assert 0 < o["tjds"]["frac"] < 1 and 0 < o["config4"]["frac"] < 1 and o["config4"]["bit_identical_run_to_run"]
-    cl = o["config4_c_layer"]
-    assert cl["n_gpus"] == 1 and all(cl["chunks_%d" % c][f]["event_ms"] > 0 for c in (1, 4)
-                                     for f in ("products_only", "products_then_allgather", "overlapped"))
-    # round 4: what the plans cost, the set-up beside the product, the speed-up keys (the same at every N), the chunk choice
-    assert j["roofline"]["plan"]["plan_bytes"] > 0 and j["roofline"]["plan"]["plan_build_ms"] > 0
-    assert j["roofline"]["setup"]["device_arrays_equal_input"] and j["roofline"]["setup"]["convert_device_ms"] > 0
-    for key in ("t1_ms", "tN_step_ms", "tN_step_after_ms", "speedup_overlapped", "speedup_after", "chunks_chosen", "plan"):
-        assert key in o["config4"], key
-    assert o["config4"]["speedup_overlapped"] == 1.0 and o["config4"]["chunks_chosen"] == 1
-    assert o["config4"]["chunks_chosen_for_n8"] in (1, 2, 4) and set(o["config4"]["eighth_of_n8"]["estimates_ms"]) == {"1", "2", "4"}
-    rm = o["survey_random_model"]
-    assert rm["bit_identical_run_to_run"] and rm["plan"]["plan_bytes"] >= 0 and rm["launches_per_product"] >= 1
-    assert "plan" in o["tjds"] and o["tjds"]["convert_device_ms"] > 0 and "plan" in o["pwt_tiled_csr"] and "plan" in o["pwt_tiled_tjds"]
-    assert "csr_vs_reference_report" not in lines[0]      # no GPU-over-reference ratio on the in-kernel clock any more
-    # round 5: the driver's parse keeps only the SCALAR keys of `roofline` -- everything a record needs is there flat
-    r = j["roofline"]
+    # every figure a record needs is a flat scalar of `roofline`
     for key in ("frac_tjds", "frac_tjds_colmajor", "frac_survey_random_model", "frac_config4", "frac_pwt_csr", "frac_pwt_tjds",
                 "ms_tjds", "ms_survey_random_model", "ms_config4",
                 "config4_t1_ms", "config4_tN_step_ms", "config4_tN_step_after_ms", "config4_tN_products_only_ms",
@@ -1297,38 +1282,69 @@ def test_bench_script_runs_small(torch):
                 "config4_c_layer_products_only_ms_1chunk", "config4_c_layer_overlapped_ms_1chunk", "config4_c_layer_after_ms_4chunk",
                 "exchange_rccl_ms", "exchange_copies_ms", "exchange_direct_ms", "c_layer_exchange_chosen",
                 "memplus_csr_us", "memplus_tjds_us", "memplus_csr_loop_wall_us", "pwt_csr_us", "config5_csr_us", "config5_both_us",
-                "exchange", "dist_backend", "rccl_ranks", "n_gpus", "self_launched", "prewarm_ms"):
-        assert key in r and not isinstance(r[key], (dict, list)), key
-    assert r["frac_tjds"] == o["tjds"]["frac"] and r["frac_config4"] == o["config4"]["frac"] and r["rccl_ranks"] == 0
-    assert r["config4_t1_ms"] == o["config4"]["t1_ms"] and r["config4_speedup_overlapped"] == 1.0 and r["self_launched"] is False
+                "exchange", "dist_backend", "rccl_ranks", "n_gpus", "self_launched", "prewarm_ms", "leg_seconds", "wall_s"):
+        assert key in r, key
+    assert r["rccl_ranks"] == 0 and r["config4_speedup_overlapped"] == 1.0 and r["self_launched"] is False
+    # the detail file: the same figures with what the line leaves out
+    o, extra = d["others"], d["extra"]
+    assert d["roofline"]["frac"] == r["frac"] and d["cpu_baseline"]["value"] == cpu["value"] and not d["errors"]
+    assert extra["full_size_parity"]["y_equals_tiled_reference_memplus_y"]
+    assert "error" not in extra["tjds"] and "error" not in extra["survey_random_model"]
+    c4, pw = extra["config4"], extra["pwt_tiled"]
+    assert c4["n_gpus"] == 1 and c4["rows"] == 300000 and c4["nnz"] == 32 * 300000 and c4["spmv_only_ms"] > 0
+    assert pw["y_equals_tiled_reference_pwt_y"] and pw["tjds"]["equals_csr_bit_for_bit"]
+    c5 = extra["config5_pwt"]
+    assert c5["y_equals_reference_report"] and 0 < c5["csr_ms_per_step"] < c5["csr_then_tjds_ms_per_step"]
+    sm_ = extra["sample_matrices"]["memplus.mtx"]
+    assert sm_["csr_avg_ms"] < sm_["csr_avg_ms_event_pairs"] and sm_["csr_agrees_with_cpu"] and sm_["tjds_agrees_with_cpu"]
+    for key in ("tjds", "config4", "config4_c_layer", "pwt_tiled_csr", "pwt_tiled_tjds", "survey_random_model", "sample_matrices_us_per_product"):
+        assert key in o and "error" not in o[key], key
+    assert r["frac_tjds"] == o["tjds"]["frac"] and r["frac_config4"] == o["config4"]["frac"] and r["config4_t1_ms"] == o["config4"]["t1_ms"]
+    assert 0 < o["tjds"]["frac"] < 1 and 0 < o["config4"]["frac"] < 1 and o["config4"]["bit_identical_run_to_run"]
+    cl = o["config4_c_layer"]
+    assert cl["n_gpus"] == 1 and all(cl["chunks_%d" % c][f]["event_ms"] > 0 for c in (1, 4)
+                                     for f in ("products_only", "products_then_allgather", "overlapped"))
+    assert d["roofline"]["plan"]["plan_bytes"] > 0 and d["roofline"]["setup"]["device_arrays_equal_input"]
+    assert o["config4"]["chunks_chosen_for_n8"] in (1, 2, 4) and set(o["config4"]["eighth_of_n8"]["estimates_ms"]) == {"1", "2", "4"}
+    rm = o["survey_random_model"]
+    assert rm["bit_identical_run_to_run"] and rm["plan"]["plan_bytes"] >= 0 and rm["launches_per_product"] >= 1
 
 
-def test_bench_starts_its_own_ranks(torch):
-    """`python bench.py --gpus 2` with no launcher around it (the driver's command shape): the script starts its two ranks
-    itself -- here over gloo, sharing the one GPU -- relays rank 0's JSON line and leaves no process behind."""
+def test_bench_budget_skips_legs_and_keeps_the_line(torch, tmp_path):
+    """--budget too small for the secondary legs: they are not started, each leaves `<leg>_error` on the line, the headline stands."""
     import json
     import sys
 
-    import psutil
     from conftest import ROOT
+
+    detail = str(tmp_path / "d.json")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--copies", "8", "--rows", "300000", "--steps", "3", "--warmup", "1",
+                        "--no-live-traffic", "--budget", "1", "--detail", detail], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = json.loads(p.stdout.splitlines()[-1])
+    r = j["roofline"]
+    assert j["value"] > 0 and 0 < r["frac"] < 1 and j["cpu_baseline"] is None
+    for leg in ("tjds", "cpu_baseline", "config4", "survey_random_model", "pwt_tiled"):
+        assert r[leg + "_error"].startswith("skipped"), leg
+    assert "frac_config4" not in r and len(p.stdout.splitlines()[-1]) < 8000
+
+
+def test_bench_starts_its_own_ranks(torch, tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (the driver's command shape): the script starts its two ranks
+    itself -- here over gloo, sharing the one GPU -- relays rank 0's compact line and leaves no process behind."""
+    import psutil
 
     env = dict(os.environ, SMVP_DIST_BACKEND="gloo")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     before = {q.pid for q in psutil.process_iter()}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--copies", "8", "--rows", "300000",
-                        "--steps", "3", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=600)
-    assert p.returncode == 0, p.stderr[-3000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    j = json.loads(lines[0])
+    j, text, d = _bench(tmp_path, ["--gpus", "2", "--copies", "8", "--rows", "300000", "--steps", "3", "--warmup", "1"], env=env)
     r = j["roofline"]
     assert j["n_gpus"] == 2 and r["n_gpus"] == 2 and r["self_launched"] is True and r["dist_backend"] == "gloo" and r["rccl_ranks"] == 0
-    assert j["extra"]["dist"]["ranks_in_group"] == 2
+    assert d["extra"]["dist"]["ranks_in_group"] == 2 and j["cpu_baseline"] is None
     for key in ("config4_t1_ms", "config4_tN_step_ms", "config4_tN_products_only_ms", "config4_speedup_overlapped",
                 "config4_speedup_after", "config4_chunks_chosen", "headline_products_only_ms", "exchange"):
         assert key in r, key
-    assert "config4_c_layer_error" not in r, r.get("config4_c_layer_error")
     assert r["config4_c_layer_overlapped_ms_1chunk"] > 0 and r["exchange_direct_ms"] > 0
     left = [q for q in psutil.process_iter(["cmdline", "name"]) if q.pid not in before and "python" in (q.info["name"] or "")
             and "bench.py" in " ".join(q.info["cmdline"] or [])]      # (python processes only: a shell's command line may name bench.py too)
@@ -1646,7 +1662,9 @@ def test_sharded_exchange_auto_is_a_measured_choice(torch):
     info = S.exchange_info()
     assert set(info["available"]) == {sm.EXCHANGE_RCCL, sm.EXCHANGE_COPIES, sm.EXCHANGE_DIRECT} and info["rccl_ranks"] == 1
     assert set(info["ms"]) == {"rccl", "copies", "direct"} and all(v > 0 for v in info["ms"].values())
-    assert info["ms"][info["active_name"]] == min(info["ms"].values())
+    # the fastest is kept -- unless it beats the starting form (RCCL) by less than 5 %: then AUTO stays where it started
+    fastest = min(info["ms"].values())
+    assert info["ms"][info["active_name"]] == fastest or (info["active"] == sm.EXCHANGE_RCCL and fastest >= 0.95 * info["ms"]["rccl"])
     S.set_x(None)
     got = {}
     for ex in (sm.EXCHANGE_RCCL, sm.EXCHANGE_COPIES, sm.EXCHANGE_DIRECT):
@@ -1927,19 +1945,11 @@ def test_sharded_rejects_bad_gpu_counts(torch):
         assert ob.fmt_g(y) == ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_1615284655.txt"))
 
 
-def test_bench_script_tjds_format(torch):
-    import json
-    import sys
-
-    from conftest import ROOT
-
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--format", "tjds", "--copies", "8", "--steps", "3",
-                        "--warmup", "1", "--no-random-model", "--no-samples", "--no-cpu-baseline", "--no-config4", "--no-pwt-tiled"],
-                       capture_output=True, text=True)
-    assert p.returncode == 0, p.stderr[-2000:]
-    j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+def test_bench_script_tjds_format(torch, tmp_path):
+    j, text, d = _bench(tmp_path, ["--format", "tjds", "--copies", "8", "--steps", "3", "--warmup", "1", "--no-random-model", "--no-samples",
+                                   "--no-cpu-baseline", "--no-config4", "--no-pwt-tiled"])
     assert j["config"]["format"] == "tjds" and "TJDS" in j["metric"] and j["roofline"]["kernel"] == "csr_stream_owner<4, 4, false>"
-    assert j["extra"]["full_size_parity"]["y_equals_tiled_reference_memplus_y"] and j["value"] > 0
+    assert d["extra"]["full_size_parity"]["y_equals_tiled_reference_memplus_y"] and j["value"] > 0
     # roofline.traffic of this line was measured in the run itself (rocprofv3 --pmc child passes) unless rocprofv3 is
     # missing; either way it can only lie between the algorithmic bytes and a few times them
     t = j["roofline"]["traffic"]
@@ -2071,6 +2081,37 @@ def test_many_iterations_use_the_timing_rings(torch, timing):
     y, ms, st = sm.tjds_compute(coo, m, n, iters=1025, timing=timing)
     assert len(ms) == 1025 and np.all(ms > 0)
     assert ob.fmt_g(y) == ob.report_y_lines(ob.read_report("smvp-toolbox_report_CSR_1615284655.txt"))
+
+
+def test_repeating_kernel_gives_up_quickly_and_the_run_falls_back(torch):
+    """The repeating kernel's barrier is bounded: with no patience at all (repeat_patience_us < 0, the test hook) every workgroup
+    that has to wait gives up, the launch says so on its top word and in the run's sticky word, the host -- which waits for the
+    FIRST launch of a run before queueing the others -- does the run over from a hipGraph, one launch per product: same y, every
+    product timed, and the whole thing takes milliseconds, not the patience of a thousand queued launches (-n 100000
+    on a shared GPU held the device for minutes).  With the default patience the same run uses the repeating kernel."""
+    import time
+
+    m, n, coo = load("memplus.mtx")
+    want = None
+    for fn in (sm.csr_compute, sm.tjds_compute):
+        y_ok, ms_ok, _ = fn(coo, m, n, iters=3000)
+        info = sm.last_run_info()
+        assert info.repeat_launches == 3 and info.repeat_gave_up == 0 and info.graph_replays == 0
+        t0 = time.perf_counter()
+        y, ms, st = fn(coo, m, n, iters=3000, repeat_patience_us=-1)
+        wall = time.perf_counter() - t0
+        info = sm.last_run_info()
+        assert info.repeat_gave_up == 1 and info.repeat_launches == 0 and info.graph_replays > 0 and info.timing == sm.TIMING_DEVICE
+        assert np.array_equal(y, y_ok) and len(ms) == 3000 and np.all(ms > 0) and 0.0005 < st.time_avg < 0.05
+        assert wall < 5.0, wall          # conversion + one abandoned launch + 3000 replayed products
+        # a single launch (no second one to protect): it gives up too, and is done over the same way
+        y1, ms1, _ = fn(coo, m, n, iters=100, repeat_patience_us=-1)
+        info = sm.last_run_info()
+        assert info.repeat_gave_up == 1 and info.graph_replays > 0 and np.array_equal(y1, y_ok) and np.all(ms1 > 0)
+        want = y_ok if want is None else want
+    # a generous patience is as good as the default
+    y, _, _ = sm.csr_compute(coo, m, n, iters=200, repeat_patience_us=10_000_000)
+    assert sm.last_run_info().repeat_launches == 1 and np.array_equal(y, want)
 
 
 def test_device_timing_agrees_with_events_and_is_the_default_for_small_launches(torch):
