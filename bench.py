@@ -137,8 +137,8 @@ class Emitter:
                 self.state["out"].flush()
 
     def _watch(self, hard):
-        while time.time() - self.state["t0"] < hard + (0.0 if self.rank == 0 else 5.0):
-            time.sleep(0.5)
+        while time.time() - self.state["t0"] < hard:
+            time.sleep(0.25)
             if self.done:
                 return
         self.state["watchdog"] = "hard deadline %.0f s passed in leg '%s'" % (hard, self.state.get("leg", "?"))
@@ -147,6 +147,8 @@ class Emitter:
         had_head = bool(self.state.get("head"))
         self.emit()
         sys.stderr.flush()
+        if self.rank == 0:
+            time.sleep(3.0)     # the other ranks leave at the same deadline: rank 0 goes last, so that none of them sees its peer vanish
         os._exit(0 if had_head or self.rank else 3)
 
 

@@ -348,9 +348,13 @@ def spawn_ranks(args, argv):
     grace = None
     why = ""
     stragglers = []
+    seen_exit = {}          # rank -> when its exit was first seen (a rank that fails AFTER rank 0 has left is a consequence, not a cause)
     while any(p.poll() is None for p in procs):
         now = time.time()
-        failed = [i for i, p in enumerate(procs) if p.poll() not in (None, 0)]
+        for i, p in enumerate(procs):
+            if p.poll() is not None:
+                seen_exit.setdefault(i, now)
+        failed = [i for i, p in enumerate(procs) if p.poll() not in (None, 0) and not (procs[0].poll() == 0 and seen_exit.get(i, now) > seen_exit.get(0, now))]
         if failed and grace is None:
             grace = now + 30.0
             why = "rank %d exited with %s" % (failed[0], procs[failed[0]].returncode)
@@ -372,11 +376,17 @@ def spawn_ranks(args, argv):
         except Exception:
             end(p)
     t.join(timeout=10)
+    now = time.time()
+    for i, p in enumerate(procs):
+        seen_exit.setdefault(i, now)
     codes = [p.returncode if p.returncode is not None else -9 for p in procs]
     have_line = any(l.startswith("{") for l in lines)
-    if codes[0] == 0 and have_line and all(c == 0 or i in stragglers for i, c in enumerate(codes)):
-        if stragglers:
-            log(0, "self-launched run: %s (ranks %s); rank 0's line stands" % (why, stragglers))
+    # rank 0 finished and its line is out: a rank that was ended here, or that failed only after rank 0 had left (its peer gone from a
+    # collective: the watchdog's case), does not take the line back; a rank that failed while rank 0 was still running does
+    after = [i for i, c in enumerate(codes) if c != 0 and (i in stragglers or seen_exit[i] > seen_exit[0])]
+    if codes[0] == 0 and have_line and all(c == 0 or i in after for i, c in enumerate(codes)):
+        if after:
+            log(0, "self-launched run: rank(s) %s ended or failed (codes %s) after rank 0 had finished; rank 0's line stands" % (after, [codes[i] for i in after]))
         return 0
     rc = 0 if all(c == 0 for c in codes) else next((c for c in codes if c > 0), 1)
     if rc == 0 and not have_line:

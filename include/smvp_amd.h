@@ -179,7 +179,7 @@ enum {
                                          build) bit-identical to main-cli.c:410-416; for a row whose col_ind is not
                                          ascending the sum is reproducible and within the rounding bound, but its
                                          order is not the serial loop's.  param: rows per workgroup of four strips
-                                         (256 ... 8192, a multiple of 4; 0 = chosen from the block's rows: the height with the best share of busy CUs x rate,
+                                         (256 ... 20480, a multiple of 4; 0 = chosen from the block's rows: the height with the best share of busy CUs x rate,
                                          which may be the one that cuts the rows into whole generations of 256 workgroups) */
     SMVP_CSR_KERNEL_BINNED = 5        /* for matrices with a band around the diagonal plus many entries far from it
                                          (anywhere in an operand much larger than the L2): the entries are kept a second

@@ -222,16 +222,25 @@ void free_sweep_plan(smvp_csr *h)
 // block's own entries).  Candidates are now also the heights that cut the rows into EXACTLY g x 256
 // workgroups, g = 1, 2, ...: 1.25 M rows as 256 workgroups of 4884 rows are one full generation.  The rate of a height in
 // between is read off the measured ones on a log scale.
+// Round 6: the taller the strip, the denser its column-sorted stream, and the more often adjacent lanes of one gather instruction
+// fall into the same line of x and leave the L1 as ONE request -- the kernel is bound by the L2s' request rate, so
+// that is time: strips of 1954 rows (mean gap 160 columns) coalesce 5 % of their gathers, strips of 4884 rows (gap 64) 12 %.
+// The 16-bit row word now spends 13 bits on the row (turns capped at 7), the four strips of a workgroup may fill the CU's LDS
+// (kSweepMaxRb rows = 160 KB of sums), and config 4 whole runs 1.979 -> 1.801 ms as 2 generations of 256 x 19532 rows.
+constexpr int kSweepMaxRb = 20480;
 double sweep_rate(int rb)
 {
-    const struct { double lg, rate; } pts[] = {{10.0, 0.70}, {11.0, 0.80}, {12.0, 0.86}, {13.0, 1.0}};
+    // (20480 rows: round 6 -- strips of up to 5120 rows, the four of a workgroup fill the CU's 160 KB of LDS; config 4 whole:
+    // 7816 rows 161.7 G gathers/s, 9768 166.1, 13024 171.2, 19536 177.7 -- profiles/r06_colsweep_tall_strips.txt)
+    const struct { double lg, rate; } pts[] = {{10.0, 0.70}, {11.0, 0.80}, {12.0, 0.86}, {13.0, 1.0}, {14.32, 1.10}};
+    constexpr int N = (int)(sizeof pts / sizeof pts[0]);
     const double lg = std::log2((double)std::max(rb, 1));
     if (lg <= pts[0].lg)
         return pts[0].rate * std::max(0.25, lg / pts[0].lg);
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i + 1 < N; ++i)
         if (lg <= pts[i + 1].lg)
             return pts[i].rate + (pts[i + 1].rate - pts[i].rate) * (lg - pts[i].lg) / (pts[i + 1].lg - pts[i].lg);
-    return pts[3].rate;
+    return pts[N - 1].rate;
 }
 
 void choose_sweep_shape(int rows, int cols, int nnz, int want_rb, int *rb, int *per_launch)
@@ -242,14 +251,14 @@ void choose_sweep_shape(int rows, int cols, int nnz, int want_rb, int *rb, int *
         floor_rb <<= 1;
     auto generations = [](int nrb) { return (nrb + 255) / 256; };
     std::vector<int> heights;
-    for (int hgt : {8192, 4096, 2048, 1024})
+    for (int hgt : {kSweepMaxRb, 16384, 8192, 4096, 2048, 1024})
         if (hgt >= floor_rb)
             heights.push_back(hgt);
     // ... and the heights of whole generations; those may be half as tall as the floor (a full chip outweighs the faster window:
     // a 312 K-row chunk of config 4 as 256 x 1224 rows 0.0975 ms, as 153 x 2048 rows 0.134; profiles/r05_colsweep_heights.txt)
     for (int g = 1; g <= 16 && rows > 0; ++g) {
         const long long want = ((long long)rows + 256ll * g - 1) / (256ll * g);  // rows per workgroup for g full generations
-        const int h4 = (int)std::min<long long>(8192, (want + 3) / 4 * 4);      // four strips per workgroup
+        const int h4 = (int)std::min<long long>(kSweepMaxRb, (want + 3) / 4 * 4);  // four strips per workgroup
         if (h4 >= std::max(1024, floor_rb / 2))
             heights.push_back(h4);
     }
@@ -560,7 +569,7 @@ bool choose_csr_kernel(smvp_csr *h, int kernel, int param)
         return false;
     if (kernel == SMVP_CSR_KERNEL_STREAM_CARRY && param != 0 && param != 1024 && param != 2048)
         return false;
-    if (kernel == SMVP_CSR_KERNEL_COLSWEEP && param != 0 && (param < 256 || param > 8192 || param % 4 != 0))
+    if (kernel == SMVP_CSR_KERNEL_COLSWEEP && param != 0 && (param < 256 || param > kSweepMaxRb || param % 4 != 0))
         return false;
     if (kernel == SMVP_CSR_KERNEL_BINNED && param < 0)
         return false;
@@ -779,7 +788,7 @@ extern "C" int smvp_csr_set_kernel(smvp_csr_t *h, int kernel, int param)
     DeviceScope on(h->device);
     if (!choose_csr_kernel(h, kernel, param))
         return smvp::fail(SMVP_ERR_INVALID, "entries per tile must be 256 (stream only), 1024 or 2048 for the kernel "
-                                            "this matrix resolves to (column sweep: 256 ... 8192 rows per block, a multiple of 4; binned: the near band, >= 0)");
+                                            "this matrix resolves to (column sweep: 256 ... 20480 rows per block, a multiple of 4; binned: the near band, >= 0)");
     const double t0 = wall_ms();
     free_sweep_plan(h);
     free_binned(h);

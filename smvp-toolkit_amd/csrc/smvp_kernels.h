@@ -14,7 +14,7 @@ constexpr int kSweepBlock = 256;   // threads per block, csr_colsweep: four wave
 constexpr int kSweepWaves = kSweepBlock / 64;
 constexpr int kSweepUnroll = 4;    // stream entries per lane and pass: a wavefront takes its strip 256 entries at a time
 constexpr int kSweepChunk = 64 * kSweepUnroll;
-constexpr int kSweepRowBits = 11;  // a strip holds at most 2048 rows (16 KB of sums in LDS) ...
+constexpr int kSweepRowBits = 13;  // a strip holds at most 8192 rows (64 KB of sums in LDS; four strips of 5120 fill a CU's 160 KB) ...
 constexpr int kSweepTurnCap = (1 << (16 - kSweepRowBits)) - 1;  // ... and the 16-bit row word carries the entry's turn, capped
 constexpr int kTjdsBlock = 256;     // permuted columns per work item
 constexpr int kTjdsDiagChunk = 8;   // jagged diagonals per work item

@@ -1577,6 +1577,13 @@ hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, con
     const size_t lds = sizeof(double) * (size_t)strip_rows * kSweepWaves;
     if (per_launch <= 0)
         per_launch = nwg;
+    if (lds > 64u * 1024) {  // strips taller than 2048 rows: more dynamic LDS than a kernel gets unasked
+        const hipError_t e = g == 4   ? hipFuncSetAttribute((const void *)csr_colsweep<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                             : g == 2 ? hipFuncSetAttribute((const void *)csr_colsweep<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                      : hipFuncSetAttribute((const void *)csr_colsweep<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+    }
     for (int first = 0; first < nwg; first += per_launch) {
         const unsigned grid = (unsigned)(nwg - first < per_launch ? nwg - first : per_launch);
 #define SMVP_SWEEP(GG)                                                                                                   \

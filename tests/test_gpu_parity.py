@@ -267,7 +267,9 @@ def test_colsweep_on_scattered_columns(torch):
     A.spmv(dx, dy)
     torch.cuda.synchronize()
     assert np.array_equal(dy.cpu().numpy(), ref)                  # 32 entries per row: the tile kernel is serial too
-    for rb, want in ((0, 2736), (8192, 8192), (2048, 2048), (4096, 4096), (1024, 1024), (3000, 3000), (1028, 1028), (256, 256)):
+    # (round 6: strips of up to 5120 rows -- four of them fill a CU's 160 KB of LDS; 13 bits of the row word, turns capped at 7)
+    for rb, want in ((0, 2736), (8192, 8192), (2048, 2048), (4096, 4096), (1024, 1024), (3000, 3000), (1028, 1028), (256, 256),
+                     (9768, 9768), (20480, 20480)):
         A.set_kernel(sm.CSR_KERNEL_COLSWEEP, rb)
         assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, want) and A.describe()[0].startswith("csr_colsweep<")
         for _ in range(2):
@@ -278,7 +280,7 @@ def test_colsweep_on_scattered_columns(torch):
     with pytest.raises(sm.SmvpError):
         A.set_kernel(sm.CSR_KERNEL_COLSWEEP, 3001)            # four strips per workgroup: a multiple of 4
     with pytest.raises(sm.SmvpError):
-        A.set_kernel(sm.CSR_KERNEL_COLSWEEP, 8196)
+        A.set_kernel(sm.CSR_KERNEL_COLSWEEP, 20484)
     A.set_kernel(sm.CSR_KERNEL_AUTO, 0)                       # AUTO again: the sweep, plan rebuilt
     assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, 2736)
     dy.fill_(float("nan"))
@@ -2164,7 +2166,7 @@ def test_config4_full_size_properties(torch):
     row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_UNIFORM, 2024, M, M, param=32)
     assert len(col_ind) == 320_000_000
     A = sm.CsrMatrix(M, M, row_ptr, col_ind, val)
-    assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, 7816)      # 1280 workgroups = five FULL generations of 256 (round 5; 8192: 5 x 245)
+    assert A.get_kernel() == (sm.CSR_KERNEL_COLSWEEP, 19532)     # 512 workgroups = two FULL generations of 256, strips of 4883 rows (round 6; round 5: 7816 = five)
     ones = torch.ones(M, dtype=torch.float64, device="cuda")
     y1, y2, ya, yb, yab = (torch.empty(M, dtype=torch.float64, device="cuda") for _ in range(5))
     A.spmv(ones, y1)

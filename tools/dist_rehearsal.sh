@@ -1,54 +1,61 @@
 #!/bin/bash
-# tools/dist_rehearsal.sh -- on the one-GPU box: bench.py's multi-rank code paths end to end (NOT a scaling measurement):
-#   1. one rank through RCCL (SMVP_FORCE_DIST=1, torch.distributed.run): communicator, chunked exchange, C-layer leg in-process
-#   2. the DRIVER'S command shape: `python3 bench.py --gpus 2` with NO launcher around it -- bench.py starts its two ranks itself
-#      (here over gloo, sharing the card); the C-layer leg in a child process of rank 0 (two virtual ranks), the chunk choice from
-#      measured products and gathers, the flat roofline.* keys a scaling record needs
-#   3. the same with four ranks (gloo), smaller matrices
-#   4. what is left running afterwards (BENCH_r02 ... r04 counted one process at the end of the run)
-# Writes gpurun_out/r05/dist_rehearsal.txt
+# tools/dist_rehearsal.sh -- on the one-GPU box: the command shape the driver uses for the scaling runs, `python3 bench.py --gpus N
+# --steps 20 --warmup 5` with NO launcher around it, end to end (NOT a scaling measurement: the ranks share one card over gloo).
+#   1. --gpus 6 at reduced size (six ranks is what this pool's process guard lets one job put on a card; the driver's N = 8
+#      differs in nothing but the number: same self-launch, same legs, the C-layer child with N virtual ranks)
+#   2. --gpus 2 at BASELINE config 4's FULL size (10 M rows): per-rank set-up here is 4x what a rank of eight builds, so the
+#      per-leg seconds bound the real run's from above (the exchange over gloo through host memory does not: ignore tN)
+#   3. --gpus 4 with a hard deadline that falls into the legs: the watchdog prints the line from what has been measured, every rank
+#      exits 0, nothing is left running
+#   4. one rank through RCCL (SMVP_FORCE_DIST=1 under torch.distributed.run): communicator + chunked exchange
+# Each: exit code, wall seconds, the line's length, its n_gpus / config4_* / exchange_* / leg_seconds keys, and a process census.
+# Writes gpurun_out/r06/dist_rehearsal.txt
 set -u
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r05; mkdir -p "$OUT"
+OUT=$R/gpurun_out/r06; mkdir -p "$OUT"
 F=$OUT/dist_rehearsal.txt
 : > "$F"
-show() {
-python3 - "$1" >> "$F" <<'PY'
+show() {   # $1 = stdout file, $2 = wall seconds
+python3 - "$1" "$2" >> "$F" <<'PY'
 import json, sys
-lines = [l for l in open(sys.argv[1]) if l.startswith("{")]
-if not lines:
+lines = open(sys.argv[1]).read().splitlines()
+print("stdout: %d line(s); wall %s s" % (len(lines), sys.argv[2]))
+if not lines or not lines[-1].startswith("{"):
     print("NO JSON LINE"); sys.exit(0)
 j = json.loads(lines[-1])
-print(json.dumps({k: j[k] for k in ("metric", "value", "n_gpus", "ms_per_step", "scaling")} | {"config": j["config"]["workload"][-80:]}))
 r = j["roofline"]
-print("roofline (flat scalars, what the driver's parse keeps): " + json.dumps({k: v for k, v in r.items() if not isinstance(v, (dict, list)) and k not in ("note", "traffic_source")}))
-for k in ("config4", "config4_c_layer", "headline_products_only"):
-    if k in r["others"]:
-        print("roofline.others.%s: %s" % (k, json.dumps(r["others"][k])))
-print("extra.dist: %s; child_processes_at_exit: %s" % (json.dumps(j["extra"].get("dist")), j["extra"].get("child_processes_at_exit")))
+print("line: %d characters; nested objects below roofline/config/cpu_baseline: %s" % (
+    len(lines[-1]), [k for o in (r, j["config"], j["cpu_baseline"] or {}) for k, v in o.items() if isinstance(v, (dict, list))]))
+print(json.dumps({k: j[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling")} | {"config.workload": j["config"]["workload"][:60]}))
+keys = [k for k in r if k.startswith(("config4_t", "config4_speedup", "config4_chunks", "config4_c_layer_step", "config4_c_layer_speedup",
+                                      "exchange", "c_layer_", "rccl_ranks", "dist_backend", "self_launched", "n_gpus", "frac", "headline_products",
+                                      "leg_seconds", "wall_s", "watchdog")) or k.endswith("_error")]
+print(json.dumps({k: r[k] for k in keys}))
 PY
 }
 census() {
   echo "processes of this user after the run ($1):" >> "$F"
-  ps -u "$(id -u)" -o pid,ppid,etime,cmd --no-headers | grep -v -E "ps -u|dist_rehearsal|grep|bash -o pipefail|sleep" | cut -c1-160 >> "$F"
+  ps -u "$(id -u)" -o pid,ppid,etime,cmd --no-headers | grep -v -E "ps -u|dist_rehearsal|grep|bash -o pipefail|sleep|cut -c" | cut -c1-160 >> "$F"
+  echo "(end of census)" >> "$F"
+}
+run() {    # $1 = tag, rest = command
+  local tag=$1; shift
+  echo "\$ $*" >> "$F"
+  local t0=$(date +%s.%N)
+  "$@" > "$OUT/reh_$tag.out" 2> "$OUT/reh_$tag.err"
+  local rc=$?
+  local t1=$(date +%s.%N)
+  echo "exit code $rc" >> "$F"
+  grep -h "without a launcher\|self-launched\|hard deadline\|skipped" "$OUT/reh_$tag.err" | cut -c1-220 >> "$F"
+  show "$OUT/reh_$tag.out" "$(python3 -c "print(round($t1 - $t0, 1))")"
+  census "$tag"
+  echo >> "$F"
 }
 cd $R
-echo '$ SMVP_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 10 --warmup 2 --no-random-model --no-samples --no-cpu-baseline --no-tjds --no-pwt-tiled --chunks 4   (one rank, backend nccl = RCCL)' >> "$F"
-SMVP_FORCE_DIST=1 timeout -k 10 500 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 10 --warmup 2 --no-random-model --no-samples --no-cpu-baseline --no-tjds --no-pwt-tiled --chunks 4 > "$OUT/reh1.out" 2> "$OUT/reh1.err" || { echo "rehearsal 1 failed" >> "$F"; tail -5 "$OUT/reh1.err" >> "$F"; }
-show "$OUT/reh1.out"
-echo >> "$F"
-echo '$ SMVP_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 5 --warmup 1 --rows 2000000   (NO launcher: bench.py starts its own two ranks; they share the card over gloo; the C-layer leg in a child of rank 0 with two virtual ranks)' >> "$F"
-SMVP_DIST_BACKEND=gloo timeout -k 10 700 python3 bench.py --gpus 2 --steps 5 --warmup 1 --rows 2000000 > "$OUT/reh2.out" 2> "$OUT/reh2.err"; echo "exit code $?" >> "$F"
-grep -h "without a launcher\|self-launched" "$OUT/reh2.err" >> "$F"
-show "$OUT/reh2.out"
-census "gloo 2"
-echo >> "$F"
-echo '$ SMVP_DIST_BACKEND=gloo python3 bench.py --gpus 4 --steps 5 --warmup 1 --copies 64 --rows 1000000 --no-cpu-baseline   (four self-launched ranks on the one card)' >> "$F"
-SMVP_DIST_BACKEND=gloo timeout -k 10 700 python3 bench.py --gpus 4 --steps 5 --warmup 1 --copies 64 --rows 1000000 --no-cpu-baseline > "$OUT/reh3.out" 2> "$OUT/reh3.err"; echo "exit code $?" >> "$F"
-show "$OUT/reh3.out"
-census "gloo 4"
-echo >> "$F"
-echo '$ python3 bench.py --steps 20 --warmup 5   (the default run, then the census: what BENCH_rNN.run.procs_at_end could be counting)' >> "$F"
-timeout -k 10 600 python3 bench.py --steps 20 --warmup 5 > "$OUT/reh4.out" 2> "$OUT/reh4.err"; echo "exit code $?" >> "$F"
-census "default run"
-cat "$F" | cut -c1-600
+export SMVP_DIST_BACKEND=gloo
+run gloo6 timeout -k 10 900 python3 bench.py --gpus 6 --steps 20 --warmup 5 --rows 1200000 --copies 96
+run gloo2_full timeout -k 10 900 python3 bench.py --gpus 2 --steps 20 --warmup 5
+run gloo4_deadline timeout -k 10 300 python3 bench.py --gpus 4 --steps 20 --warmup 5 --rows 2000000 --copies 96 --hard-deadline 40
+unset SMVP_DIST_BACKEND
+SMVP_FORCE_DIST=1 run rccl1 timeout -k 10 500 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 10 --warmup 2 --no-random-model --no-samples --no-cpu-baseline --no-tjds --no-pwt-tiled --chunks 4
+cut -c1-400 "$F"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # [PAT=substring] [BENCH_ARGS=..] tools/profile_bench.sh TAG  -- run on the GPU box (through gpurun): per-kernel times and HBM traffic of bench.py's
 # headline workload.  Writes gpurun_out/profile_TAG/{kernel_stats.csv, pmc_summary.txt, traffic.json, bench.json}.
-#   1. rocprofv3 --kernel-trace --stats on `bench.py --no-random-model --no-tjds --no-cpu-baseline`
+#   1. rocprofv3 --kernel-trace --stats on `bench.py --no-random-model --no-tjds --no-cpu-baseline` (bench.json = that process's line)
 #   2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, TCC, SQ ...) on the same command, fewer steps
 # FETCH_SIZE is doubled (gfx950 tallies 128-B reads at 64 B, MI355X_MICROARCH.md "HBM"); WRITE_SIZE is exact.
 set -u
@@ -12,9 +12,10 @@ mkdir -p "$OUT"
 ARGS="--no-live-traffic --no-c-layer --no-random-model --no-tjds --no-cpu-baseline --no-samples --no-config4 --no-pwt-tiled ${BENCH_ARGS:-}"
 PAT=${PAT:-csr_stream_owner<8, 5}   # kernel-name substring the PMC summary is taken over; several, separated by '|', for a product of
                                     # several kernels (the binned plan): their per-launch means are added
-python3 $R/bench.py --steps 100 --warmup 10 $ARGS > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo "bench failed"; tail -5 "$OUT/bench.err"; exit 1; }
+# ONE process gives both the kernel trace and the bench line (bench.json = the stdout of the traced run): the profile's average
+# duration and the line's ms_per_launch can be reconciled without a run-to-run or box-to-box caveat
 cd /tmp; export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 $R/bench.py --steps 100 --warmup 10 $ARGS > "$OUT/trace.log" 2>&1 || echo "kernel-trace pass failed"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 $R/bench.py --steps 100 --warmup 10 --detail "$OUT/bench_detail.json" $ARGS > "$OUT/bench.json" 2> "$OUT/trace.log" || { echo "kernel-trace pass failed"; tail -5 "$OUT/trace.log"; exit 1; }
 cp "$OUT/trace/t_kernel_stats.csv" "$OUT/kernel_stats.csv" 2>/dev/null
 cd $R
 bash tools/pmc_passes.sh gpurun_out/profile_$TAG/pmc -- python3 $R/bench.py --steps 10 --warmup 2 $ARGS > /dev/null
