@@ -4,6 +4,12 @@
 // (main-cli.c:114-130) and generateReportText (main-cli.c:246-320).  The report
 // text is byte-compatible with the reference's: tests compare it against the
 // committed files in output-test/ with the timing and timestamp lines masked.
+//
+// The five timing lines print the stats of whatever time_each_ms[] the caller hands in.  From smvp_*_compute under
+// SMVP_TIMING_AUTO that is, for launches of up to 4096 workgroups (the reference's own sample matrices), the IN-KERNEL
+// window of each product -- shorter than the host-side clock_gettime bracket of main-cli.c:408-419 by the launch
+// (memplus.mtx: 2.9 us against 4.4 us of loop wall per product).  SMVP_TIMING_EVENTS (CLI: --timing events) gives the
+// host-comparable figure; INTEGRATION.md section 2 says which to read when comparing with output-test/*.txt.
 #include "smvp_common.h"
 
 #include <cmath>
