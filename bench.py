@@ -118,6 +118,9 @@ def compact_line(state):
     return text
 
 
+DYING = threading.Event()      # set by the watchdog: it is ending this process with an exit code of its own
+
+
 class Emitter:
     """Prints the compact line exactly once -- from main() when the legs are through, or from the watchdog at the hard deadline."""
 
@@ -141,15 +144,14 @@ class Emitter:
             time.sleep(0.25)
             if self.done:
                 return
+        DYING.set()     # (from here on an exception in the main thread -- its peers are leaving too -- must not decide the exit code)
         self.state["watchdog"] = "hard deadline %.0f s passed in leg '%s'" % (hard, self.state.get("leg", "?"))
         self.state["errors"].setdefault(self.state.get("leg", "run"), "did not finish before the hard deadline")
         log(self.rank, self.state["watchdog"] + ": printing the line from what has been measured")
         had_head = bool(self.state.get("head"))
         self.emit()
         sys.stderr.flush()
-        if self.rank == 0:
-            time.sleep(3.0)     # the other ranks leave at the same deadline: rank 0 goes last, so that none of them sees its peer vanish
-        os._exit(0 if had_head or self.rank else 3)
+        os._exit(0 if had_head or self.rank else 3)     # every rank leaves at the same deadline
 
 
 def write_detail(state):
@@ -338,4 +340,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException:
+        if DYING.is_set():      # the watchdog has fired (the peers are going away under this thread's collectives): its exit code counts
+            time.sleep(30.0)
+        raise
