@@ -180,7 +180,13 @@ enum {
                                          ascending the sum is reproducible and within the rounding bound, but its
                                          order is not the serial loop's.  param: rows per workgroup of four strips
                                          (256 ... 20480, a multiple of 4; 0 = chosen from the block's rows: the height with the best share of busy CUs x rate,
-                                         which may be the one that cuts the rows into whole generations of 256 workgroups) */
+                                         which may be the one that cuts the rows into whole generations of 256 workgroups).
+                                         SMVP_CSR_SWEEP_PARTS(rb, parts), parts = 2 or 4 (rb * parts <= 20480): the workgroup's
+                                         wavefronts share two strips / one strip, each taking a half / quarter of the columns
+                                         into partial sums of its own -- strips 2x / 4x as tall for the same rows per workgroup,
+                                         which is what a block of few rows (one rank's share of a sharded matrix) lacks; a row's
+                                         sum is then its partial sums added part by part: the same from run to run, inside the
+                                         rounding bound, NOT bit-identical to the serial loop.  Never picked by AUTO */
     SMVP_CSR_KERNEL_BINNED = 5        /* for matrices with a band around the diagonal plus many entries far from it
                                          (anywhere in an operand much larger than the L2): the entries are kept a second
                                          time, split by |column - row| > band.  The near part is summed out of a row
@@ -368,6 +374,8 @@ int smvp_sharded_info(const smvp_sharded_t *h, int *ngpus, int *rows_per_gpu); /
 /* bounds[ngpus + 1] of the row blocks and chunk_bounds[ngpus * (chunks + 1)] of their chunks, global rows (NULL = skip) */
 int smvp_sharded_layout(const smvp_sharded_t *h, int *chunks, int *bounds, int *chunk_bounds);
 void smvp_sharded_destroy(smvp_sharded_t *h);
+
+#define SMVP_CSR_SWEEP_PARTS(rows_per_block, parts) ((rows_per_block) | (((parts) == 4 ? 2 : (parts) == 2 ? 1 : 0) << 24))
 
 /* ------------------------------------------------ reference-shaped entry points */
 typedef struct smvp_run_opts {

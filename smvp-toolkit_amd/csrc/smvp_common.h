@@ -17,8 +17,8 @@ namespace smvp {
 int build_row_inverse(const int *d_row_ind, int nnz, int rows, int *d_inv_ptr, int *d_inv_pos, ihipStream_t *stream);
 int build_row_gather_plan(const int *d_row_ind, const int *d_start_pos, int num_diag, int nnz, int rows,
                           int *d_seg_ptr, int *d_pos, int *d_kcol, ihipStream_t *stream);
-int build_colsweep_plan(const int *d_row_ptr, const int *d_col_ind, const double *d_val, int rows, int nnz, int strip_rows,
-                        int chunk, int row_bits, int turn_cap, long long *d_strip_ptr, int *d_e_col, double *d_e_val,
+int build_colsweep_plan(const int *d_row_ptr, const int *d_col_ind, const double *d_val, int rows, int cols, int nnz, int strip_rows,
+                        int parts, int chunk, int row_bits, int turn_cap, long long *d_strip_ptr, int *d_e_col, double *d_e_val,
                         unsigned short *d_e_row, ihipStream_t *stream);
 int sort_tile_windows(const int *d_pos, int nnz, int tile, const int *d_start_pos, int num_diag, int slot_bits,
                       const double *d_val, int cache_min_tiles, int *d_pos_sorted, int *d_meta, int *d_cache_ptr,

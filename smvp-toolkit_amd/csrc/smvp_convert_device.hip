@@ -834,12 +834,14 @@ __global__ __launch_bounds__(256) void sweep_gather(const u64 *__restrict__ key,
 // the order of main-cli.c:410-416 -- whatever else is in flight.  Turns from turn_cap on are stored as turn_cap.
 __global__ __launch_bounds__(256) void sweep_turns(const u64 *__restrict__ key, const long long *__restrict__ strip_ptr,
                                                    const unsigned short *__restrict__ row_sorted, int nnz, int chunk,
-                                                   int row_bits, int turn_cap, unsigned short *__restrict__ e_row)
+                                                   int row_bits, int turn_cap, int parts, unsigned part_width,
+                                                   unsigned short *__restrict__ e_row)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nnz)
         return;
-    const long long a = strip_ptr[(unsigned)(key[i] >> 32)];
+    // the stream this entry belongs to: its strip's, or (parts > 1) that of its strip's column part
+    const long long a = strip_ptr[(unsigned)(key[i] >> 32) * (unsigned)parts + (unsigned)(key[i] & 0xffffffffu) / part_width];
     const long long first = a + ((long long)i - a) / chunk * chunk;
     const unsigned short mine = row_sorted[i];
     int turn = 0;
@@ -858,6 +860,33 @@ __global__ __launch_bounds__(256) void sweep_strip_bounds(const int *__restrict_
     strip_ptr[b] = row_ptr[r < rows ? r : rows];
 }
 
+// parts > 1: stream v = strip * parts + part holds the strip's entries whose column lies in [part * part_width, (part + 1) * part_width);
+// the sorted keys of a strip are one run, so a stream starts at the first key of the run whose column reaches its part
+__global__ __launch_bounds__(256) void sweep_part_bounds(const u64 *__restrict__ key, const int *__restrict__ row_ptr, int rows, int nnz,
+                                                         int strip_rows, int nstrips, int parts, unsigned part_width,
+                                                         long long *__restrict__ stream_ptr)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v > nstrips * parts)
+        return;
+    if (v == nstrips * parts) {
+        stream_ptr[v] = nnz;
+        return;
+    }
+    const int strip = v / parts, part = v % parts;
+    const long long r0 = (long long)strip * strip_rows, r1 = r0 + strip_rows;
+    long long lo = row_ptr[r0 < rows ? r0 : rows], hi = row_ptr[r1 < rows ? r1 : rows];
+    const unsigned first_col = (unsigned)part * part_width;
+    while (lo < hi) {  // first entry of the strip whose column is >= first_col
+        const long long mid = (lo + hi) >> 1;
+        if ((unsigned)(key[mid] & 0xffffffffu) < first_col)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    stream_ptr[v] = lo;
+}
+
 }  // namespace
 
 namespace smvp {
@@ -865,14 +894,17 @@ namespace smvp {
 // Plan of the column-swept CSR kernel (csr_colsweep): the entries a second time, every strip of strip_rows rows (one
 // wavefront's share) sorted by column (ties in input order), each with its row's number inside the strip and its turn
 // inside its chunk of `chunk` stream entries (see sweep_turns), packed as row | turn << row_bits;
-// strip_ptr[nstrips + 1] = where each strip's stream starts.
-int build_colsweep_plan(const int *d_row_ptr, const int *d_col_ind, const double *d_val, int rows, int nnz, int strip_rows,
-                        int chunk, int row_bits, int turn_cap, long long *d_strip_ptr, int *d_e_col, double *d_e_val,
+// strip_ptr[nstrips + 1] = where each strip's stream starts.  parts > 1 (column parts, round 6): every strip's stream is cut at the
+// columns part * ceil(cols / parts) into `parts` streams of their own (turns counted per stream) and d_strip_ptr has
+// nstrips * parts + 1 entries -- the kernel then gives each of a strip's parts to a wavefront of its own.
+int build_colsweep_plan(const int *d_row_ptr, const int *d_col_ind, const double *d_val, int rows, int cols, int nnz, int strip_rows,
+                        int parts, int chunk, int row_bits, int turn_cap, long long *d_strip_ptr, int *d_e_col, double *d_e_val,
                         unsigned short *d_e_row, hipStream_t st)
 {
     if (strip_rows < 1 || strip_rows > (1 << row_bits) || row_bits < 1 || row_bits > 15 || chunk < 64 ||
-        turn_cap != (1 << (16 - row_bits)) - 1)
+        turn_cap != (1 << (16 - row_bits)) - 1 || (parts != 1 && parts != 2 && parts != 4))
         return smvp::fail(SMVP_ERR_INVALID, "build_colsweep_plan: bad strip shape");
+    const unsigned part_width = (unsigned)std::max(1, (int)(((long long)std::max(cols, 1) + parts - 1) / parts));
     const int nstrips = (rows + strip_rows - 1) / strip_rows;
     hipLaunchKernelGGL(sweep_strip_bounds, dim3(blocks_for((long long)nstrips + 1)), dim3(256), 0, st, d_row_ptr, rows,
                        strip_rows, nstrips, d_strip_ptr);
@@ -898,10 +930,17 @@ int build_colsweep_plan(const int *d_row_ptr, const int *d_col_ind, const double
         HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, i0, i1, (size_t)nnz, 0u, bits, st));
         hipLaunchKernelGGL(sweep_gather, dim3(blocks_for(nnz)), dim3(256), 0, st, k1, i1, d_val, lr, nnz, d_e_col, d_e_val, lr_sorted);
         HIP_TRY(hipGetLastError());
+        if (parts > 1) {
+            hipLaunchKernelGGL(sweep_part_bounds, dim3(blocks_for((long long)nstrips * parts + 1)), dim3(256), 0, st, k1, d_row_ptr, rows, nnz,
+                               strip_rows, nstrips, parts, part_width, d_strip_ptr);
+            HIP_TRY(hipGetLastError());
+        }
         hipLaunchKernelGGL(sweep_turns, dim3(blocks_for(nnz)), dim3(256), 0, st, k1, d_strip_ptr, lr_sorted, nnz, chunk, row_bits,
-                           turn_cap, d_e_row);
+                           turn_cap, parts, part_width, d_e_row);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));
+    } else if (parts > 1) {
+        HIP_TRY(hipMemsetAsync(d_strip_ptr, 0, sizeof(long long) * ((size_t)nstrips * parts + 1), st));
     }
     HIP_TRY(hipStreamSynchronize(st));
     return SMVP_OK;

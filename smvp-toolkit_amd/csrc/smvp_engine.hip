@@ -158,6 +158,7 @@ struct smvp_csr {
     // COLSWEEP: the entries a second time, every strip of sweep_rb / 4 rows sorted by column (built on the device);
     // sweep_rb = rows per workgroup (four wavefronts, one strip each)
     int sweep_rb = 0, sweep_per_launch = 0;
+    int sweep_parts = 1;       // COLSWEEP: column parts per strip (1: every row summed in the serial loop's order; 2 / 4: see sweep_param)
     double spread = -2.0;  // share of gathers that pull their own line of x (csr_gather_spread); -2: not measured yet
     long long *d_sweep_ptr = nullptr;
     int *d_sweep_col = nullptr;
@@ -284,21 +285,45 @@ void choose_sweep_shape(int rows, int cols, int nnz, int want_rb, int *rb, int *
     *per_launch = std::max(1, (nrb + gen - 1) / gen);
 }
 
-int build_sweep_plan(smvp_csr *h, int want_rb)
+// The column sweep's kernel parameter: rows per workgroup (a multiple of 4, 0 = chosen) in the low 24 bits and, above them, log2 of
+// the COLUMN PARTS per strip (round 6).  With parts = 1 a workgroup's four wavefronts own four strips; with parts = 2 / 4 they own
+// two strips / one strip whose stream is cut into column halves / quarters, one wavefront and one array of partial sums each:
+// the strip is 2x / 4x as tall for the same rows per workgroup -- a block of rows too short to fill the LDS with four strips
+// (one rank's eighth of config 4: 256 workgroups x 4884 rows = four strips of 1221) gets the denser streams of a tall strip
+// (one strip of 4884) -- and a row's sum is its partial sums added part by part: reproducible, inside the rounding bound, no
+// longer the serial loop's bits.  Never chosen by AUTO (which keeps the serial order); SMVP_CSR_SWEEP_PARTS(rb, parts) asks for it.
+constexpr int kSweepPartsShift = 24;
+inline int sweep_param_rb(int param) { return param & ((1 << kSweepPartsShift) - 1); }
+inline int sweep_param_parts(int param) { return 1 << ((param >> kSweepPartsShift) & 3); }
+bool sweep_param_ok(int param)
+{
+    const int rb = sweep_param_rb(param), parts = sweep_param_parts(param);
+    if (param < 0 || (param >> kSweepPartsShift) > 2)
+        return false;
+    if (rb == 0)
+        return true;  // (height chosen; the parts are honoured where the chosen height leaves room for them)
+    return rb >= 256 && rb % 4 == 0 && (long long)rb * parts <= kSweepMaxRb;
+}
+
+int build_sweep_plan(smvp_csr *h, int want)
 {
     free_sweep_plan(h);
+    const int want_rb = sweep_param_rb(want);
+    h->sweep_parts = sweep_param_parts(want);
     choose_sweep_shape(h->rows, h->cols, h->nnz, want_rb, &h->sweep_rb, &h->sweep_per_launch);
-    const int strip_rows = h->sweep_rb / smvp::kSweepWaves;
+    while (h->sweep_parts > 1 && (long long)h->sweep_rb * h->sweep_parts > kSweepMaxRb)
+        h->sweep_parts >>= 1;  // (a chosen height may leave room for fewer parts than asked)
+    const int strip_rows = h->sweep_rb * h->sweep_parts / smvp::kSweepWaves;
     h->sweep_g = smvp::sweep_chunks_in_flight(strip_rows);
     const int nstrips = (h->rows + strip_rows - 1) / strip_rows;
     const size_t n = (size_t)std::max(h->nnz, 4);
-    if (hipMalloc((void **)&h->d_sweep_ptr, ((size_t)nstrips + 2) * sizeof(long long)) != hipSuccess ||
+    if (hipMalloc((void **)&h->d_sweep_ptr, ((size_t)nstrips * h->sweep_parts + 2) * sizeof(long long)) != hipSuccess ||
         hipMalloc((void **)&h->d_sweep_col, n * sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&h->d_sweep_val, n * sizeof(double)) != hipSuccess ||
         hipMalloc((void **)&h->d_sweep_row, n * sizeof(unsigned short)) != hipSuccess)
         return smvp::fail(SMVP_ERR_ALLOC, "cannot allocate the column-sweep plan (%d entries)", h->nnz);
-    return smvp::build_colsweep_plan(h->d_row_ptr, h->d_col_ind, h->d_val, h->rows, h->nnz, strip_rows, smvp::kSweepChunk, smvp::kSweepRowBits, smvp::kSweepTurnCap, h->d_sweep_ptr,
-                                     h->d_sweep_col, h->d_sweep_val, h->d_sweep_row, nullptr);
+    return smvp::build_colsweep_plan(h->d_row_ptr, h->d_col_ind, h->d_val, h->rows, h->cols, h->nnz, strip_rows, h->sweep_parts, smvp::kSweepChunk,
+                                     smvp::kSweepRowBits, smvp::kSweepTurnCap, h->d_sweep_ptr, h->d_sweep_col, h->d_sweep_val, h->d_sweep_row, nullptr);
 }
 
 // Share of the gathers of a (large) CSR matrix that pull their own 128-byte line of x through the L2, estimated on
@@ -569,7 +594,7 @@ bool choose_csr_kernel(smvp_csr *h, int kernel, int param)
         return false;
     if (kernel == SMVP_CSR_KERNEL_STREAM_CARRY && param != 0 && param != 1024 && param != 2048)
         return false;
-    if (kernel == SMVP_CSR_KERNEL_COLSWEEP && param != 0 && (param < 256 || param > kSweepMaxRb || param % 4 != 0))
+    if (kernel == SMVP_CSR_KERNEL_COLSWEEP && !sweep_param_ok(param))
         return false;
     if (kernel == SMVP_CSR_KERNEL_BINNED && param < 0)
         return false;
@@ -827,7 +852,7 @@ extern "C" int smvp_csr_get_kernel(const smvp_csr_t *h, int *kernel, int *param)
         *kernel = h->kernel;
     if (param)
         *param = h->kernel == SMVP_CSR_KERNEL_VECTOR ? h->lanes_per_row
-                 : h->kernel == SMVP_CSR_KERNEL_COLSWEEP ? h->sweep_rb
+                 : h->kernel == SMVP_CSR_KERNEL_COLSWEEP ? (h->sweep_rb | ((h->sweep_parts == 4 ? 2 : h->sweep_parts == 2 ? 1 : 0) << kSweepPartsShift))
                  : h->kernel == SMVP_CSR_KERNEL_BINNED   ? h->bin.band
                                                          : h->vpt * smvp::kStreamBlock;
     return SMVP_OK;
@@ -949,7 +974,7 @@ static int csr_spmv_impl(smvp_csr_t *h, const double *d_x, double *d_y, void *st
         e = smvp::launch_binned_sums(h->bin, d_y, st);
     } else if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP)
         e = smvp::launch_csr_colsweep(h->d_sweep_ptr, h->d_sweep_col, h->d_sweep_val, h->d_sweep_row, d_x, d_y, h->rows,
-                                      h->sweep_rb / smvp::kSweepWaves, h->sweep_per_launch, h->sweep_g, st);
+                                      h->sweep_rb * h->sweep_parts / smvp::kSweepWaves, h->sweep_parts, h->sweep_per_launch, h->sweep_g, st);
     else if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
         e = smvp::launch_csr_vector(h->lanes_per_row, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y, h->rows, st);
     else if (h->kernel == SMVP_CSR_KERNEL_STREAM) {
@@ -985,7 +1010,10 @@ extern "C" int smvp_csr_describe(const smvp_csr_t *h, char *kernel_name, size_t 
                      h->near ? h->near->vpt : 0, h->near ? (h->near->d_col16 ? smvp::kFlavorCsr16 : h->near->flavor) : 0,
                      h->bin.slots, h->bin.threads_b);
         else if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP)
-            snprintf(kernel_name, cap, "csr_colsweep<%d>", h->sweep_g);
+            if (h->sweep_parts > 1)
+                snprintf(kernel_name, cap, "csr_colsweep<%d> (%d column parts)", h->sweep_g, h->sweep_parts);
+            else
+                snprintf(kernel_name, cap, "csr_colsweep<%d>", h->sweep_g);
         else if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
             snprintf(kernel_name, cap, "csr_vector_rows<%d>", h->lanes_per_row);
         else if (h->kernel == SMVP_CSR_KERNEL_STREAM)
@@ -1026,8 +1054,8 @@ static double csr_plan_bytes(const smvp_csr_t *h)
     if (h->kernel == SMVP_CSR_KERNEL_BINNED)
         return (double)h->bin.plan_bytes + (h->near ? csr_plan_bytes(h->near) : 0.0);
     if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP) {
-        const int strip_rows = std::max(1, h->sweep_rb / smvp::kSweepWaves);
-        return 14.0 * n + 8.0 * ((h->rows + strip_rows - 1) / strip_rows + 2);
+        const int strip_rows = std::max(1, h->sweep_rb * h->sweep_parts / smvp::kSweepWaves);
+        return 14.0 * n + 8.0 * ((double)((h->rows + strip_rows - 1) / strip_rows) * h->sweep_parts + 2);
     }
     if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
         return 0.0;

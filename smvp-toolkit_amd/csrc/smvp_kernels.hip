@@ -1451,21 +1451,23 @@ template <int G>
 __global__ __launch_bounds__(kSweepBlock) void csr_colsweep(
     const long long *__restrict__ strip_ptr, const int *__restrict__ e_col, const double *__restrict__ e_val,
     const unsigned short *__restrict__ e_row, const double *__restrict__ x, double *__restrict__ y, int rows, int strip_rows,
-    int nstrips, int wg_first)
+    int nstrips, int wg_first, int parts)
 {
     constexpr int U = kSweepUnroll, E = G * U;
     constexpr long long STEP = (long long)G * kSweepChunk;
     extern __shared__ double sums_all[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // `strip` numbers the STREAMS: strip * 1 (parts == 1: a stream is a strip's) or real strip * parts + column part
     const int strip = (wg_first + (int)blockIdx.x) * kSweepWaves + wave;
-    if (strip >= nstrips)
-        return;  // (no barrier anywhere in this kernel)
+    const bool live = strip < nstrips * parts;
+    if (!live && parts == 1)
+        return;  // (no barrier in the one-part form)
     // volatile: every access is issued where it stands -- another lane's earlier store must be seen; the LDS address
     // space is spelled out so that these stay ds_read / ds_write
     typedef __attribute__((address_space(3))) volatile double lds_double;
     lds_double *sums = (lds_double *)sums_all + (size_t)wave * strip_rows;
-    const long long a = strip_ptr[strip], z = strip_ptr[strip + 1];
+    const long long a = live ? strip_ptr[strip] : 0, z = live ? strip_ptr[strip + 1] : 0;
 
     // entry e of an iteration starting at `base`: stream position base + e * 64 + lane; w = row | turn << kSweepRowBits,
     // -1 where the stream has ended
@@ -1548,9 +1550,28 @@ __global__ __launch_bounds__(kSweepBlock) void csr_colsweep(
             w[e] = wn[e];
         }
     }
-    const long long r0 = (long long)strip * strip_rows;
-    for (int i = lane; i < strip_rows && r0 + i < rows; i += 64)
-        __builtin_nontemporal_store(sums[i], &y[r0 + i]);
+    if (parts == 1) {
+        const long long r0 = (long long)strip * strip_rows;
+        for (int i = lane; i < strip_rows && r0 + i < rows; i += 64)
+            __builtin_nontemporal_store(sums[i], &y[r0 + i]);
+        return;
+    }
+    // Column parts: the wavefronts w * parts ... w * parts + parts - 1 of this workgroup hold the partial sums of ONE strip over
+    // their parts of the columns (each summed in ascending column order); a row's sum is its partial sums added in the
+    // order of the parts -- ascending columns still, but associated part by part: reproducible from run to run, within the
+    // rounding bound, NOT the serial loop's bits.
+    __syncthreads();
+    const int strips_here = kSweepWaves / parts;
+    lds_double *all = (lds_double *)sums_all;
+    for (int s = 0; s < strips_here; ++s) {
+        const long long r0 = ((long long)(wg_first + (int)blockIdx.x) * strips_here + s) * strip_rows;
+        for (int i = (int)threadIdx.x; i < strip_rows && r0 + i < rows; i += kSweepBlock) {
+            double acc = all[(size_t)(s * parts) * strip_rows + i];
+            for (int q = 1; q < parts; ++q)
+                acc += all[(size_t)(s * parts + q) * strip_rows + i];
+            __builtin_nontemporal_store(acc, &y[r0 + i]);
+        }
+    }
 }
 
 // Chunks in flight per wavefront.  A launch generation is one workgroup per CU (four wavefronts): with tall strips two chunks
@@ -1568,12 +1589,14 @@ int sweep_chunks_in_flight(int strip_rows)
 }
 
 hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, const double *e_val, const unsigned short *e_row,
-                               const double *x, double *y, int rows, int strip_rows, int per_launch, int g, hipStream_t stream)
+                               const double *x, double *y, int rows, int strip_rows, int parts, int per_launch, int g, hipStream_t stream)
 {
     if (rows <= 0)
         return hipSuccess;
+    if (parts != 1 && parts != 2 && parts != 4)
+        return hipErrorInvalidValue;
     const int nstrips = (rows + strip_rows - 1) / strip_rows;
-    const int nwg = (nstrips + kSweepWaves - 1) / kSweepWaves;
+    const int nwg = (int)(((long long)nstrips * parts + kSweepWaves - 1) / kSweepWaves);
     const size_t lds = sizeof(double) * (size_t)strip_rows * kSweepWaves;
     if (per_launch <= 0)
         per_launch = nwg;
@@ -1588,7 +1611,7 @@ hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, con
         const unsigned grid = (unsigned)(nwg - first < per_launch ? nwg - first : per_launch);
 #define SMVP_SWEEP(GG)                                                                                                   \
     hipLaunchKernelGGL(csr_colsweep<GG>, dim3(grid), dim3(kSweepBlock), lds, stream, strip_ptr, e_col, e_val, e_row, x, y, \
-                       rows, strip_rows, nstrips, first)
+                       rows, strip_rows, nstrips, first, parts)
         if (g == 4)
             SMVP_SWEEP(4);
         else if (g == 2)

@@ -29,6 +29,11 @@ TIMING_AUTO, TIMING_EVENTS, TIMING_DEVICE, TIMING_DEVICE_GRAPH = 0, 1, 2, 3
 COO_DTYPE = np.dtype([("row", "<i4"), ("col", "<i4"), ("val", "<f8")], align=True)
 
 
+def sweep_parts(rows_per_block, parts):
+    """SMVP_CSR_SWEEP_PARTS: the column sweep's kernel parameter with 2 or 4 column parts per strip (include/smvp_amd.h)."""
+    return int(rows_per_block) | ({1: 0, 2: 1, 4: 2}[int(parts)] << 24)
+
+
 class TimeStats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("time_total", "time_avg", "time_stdev", "time_min", "time_max")]
 

@@ -277,6 +277,25 @@ def test_colsweep_on_scattered_columns(torch):
             A.spmv(dx, dy)
             torch.cuda.synchronize()
             assert np.array_equal(dy.cpu().numpy(), ref)
+    # column parts (round 6, never AUTO): the workgroup's wavefronts share two strips / one strip, each taking a half / quarter of the
+    # columns into partial sums of its own; a row's sum is its partial sums added part by part -- the same from run to run and
+    # inside the rounding bound, not the serial loop's bits
+    scale = ob.csr_spmv(row_ptr, col_ind, np.abs(val), np.abs(x))
+    for rb, parts in ((2736, 2), (2736, 4), (1024, 4), (5120, 4), (10240, 2), (0, 4)):
+        A.set_kernel(sm.CSR_KERNEL_COLSWEEP, sm.sweep_parts(rb, parts))
+        got_rb, got_parts = A.get_kernel()[1] & 0xffffff, 1 << (A.get_kernel()[1] >> 24)
+        assert (got_rb, got_parts) == (rb or 2736, parts) and "%d column parts" % parts in A.describe()[0]
+        runs = []
+        for _ in range(2):
+            dy.fill_(float("nan"))
+            A.spmv(dx, dy)
+            torch.cuda.synchronize()
+            runs.append(dy.cpu().numpy())
+        assert np.array_equal(runs[0], runs[1]) and np.all(np.abs(runs[0] - ref) <= 1e-12 * scale)
+        assert not np.array_equal(runs[0], ref) or parts == 1            # (association differs: some row's last bit does)
+    for bad in (sm.sweep_parts(5124, 4), sm.sweep_parts(10244, 2), 3 << 24, sm.sweep_parts(2734, 2)):
+        with pytest.raises(sm.SmvpError):
+            A.set_kernel(sm.CSR_KERNEL_COLSWEEP, bad)
     with pytest.raises(sm.SmvpError):
         A.set_kernel(sm.CSR_KERNEL_COLSWEEP, 3001)            # four strips per workgroup: a multiple of 4
     with pytest.raises(sm.SmvpError):

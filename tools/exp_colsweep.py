@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--rb", default="0")
     ap.add_argument("--g", default="0", help="chunks in flight per wavefront (development switch SMVP_SWEEP_G), comma list")
     ap.add_argument("--repeat", type=int, default=1)
+    ap.add_argument("--parts", default="1", help="column parts per strip (1, 2, 4), comma list")
     a = ap.parse_args()
     import torch
     import smvp_toolkit_amd as sm
@@ -80,9 +81,9 @@ def main():
         print("# near part (%d entries) on the tile kernel: %.4f ms" % (int((~far).sum()), t_near), flush=True)
         y_ref = y_ref - y_near
         nnz = int(far.sum())
-    for rb, g in [(int(s), g) for s in a.rb.split(",") for g in a.g.split(",") * a.repeat]:
+    for rb, g, parts in [(int(s), g, int(p)) for s in a.rb.split(",") for p in a.parts.split(",") for g in a.g.split(",") * a.repeat]:
         os.environ["SMVP_SWEEP_G"] = g
-        S.set_kernel(sm.CSR_KERNEL_COLSWEEP, rb)
+        S.set_kernel(sm.CSR_KERNEL_COLSWEEP, sm.sweep_parts(rb, parts))
         y.fill_(float("nan"))
         S.spmv(x, y, stream=st)
         torch.cuda.synchronize()
@@ -93,8 +94,8 @@ def main():
         assert torch.equal(y, y2), "not the same bits from run to run"
         ms = timeit(torch, lambda: S.spmv(x, y, stream=st))
         tot = ms + t_near
-        print("colsweep G=%s rows/block %5d (asked %d): %.4f ms  %.1f G gathers/s  max err %.1e  |  whole product %.4f ms = %.1f %% of 8 TB/s" % (
-            g, S.get_kernel()[1], rb, ms, nnz / ms * 1e-6, err, tot, alg / tot * 1e-6 / 80), flush=True)
+        print("colsweep G=%s parts %d rows/block %5d (asked %d): %.4f ms  %.1f G gathers/s  max err %.1e  |  whole product %.4f ms = %.1f %% of 8 TB/s" % (
+            g, 1 << (S.get_kernel()[1] >> 24), S.get_kernel()[1] & 0xffffff, rb, ms, nnz / ms * 1e-6, err, tot, alg / tot * 1e-6 / 80), flush=True)
 
 
 if __name__ == "__main__":
