@@ -223,11 +223,13 @@ void free_sweep_plan(smvp_csr *h)
 // block's own entries).  Candidates are now also the heights that cut the rows into EXACTLY g x 256
 // workgroups, g = 1, 2, ...: 1.25 M rows as 256 workgroups of 4884 rows are one full generation.  The rate of a height in
 // between is read off the measured ones on a log scale.
-// Round 6: the taller the strip, the denser its column-sorted stream, and the more often adjacent lanes of one gather instruction
-// fall into the same line of x and leave the L1 as ONE request -- the kernel is bound by the L2s' request rate, so
-// that is time: strips of 1954 rows (mean gap 160 columns) coalesce 5 % of their gathers, strips of 4884 rows (gap 64) 12 %.
-// The 16-bit row word now spends 13 bits on the row (turns capped at 7), the four strips of a workgroup may fill the CU's LDS
-// (kSweepMaxRb rows = 160 KB of sums), and config 4 whole runs 1.979 -> 1.801 ms as 2 generations of 256 x 19532 rows.
+// Round 6: strips as tall as the LDS allows.  Every generation of workgroups makes all eight L2s pull all of x again, and a
+// generation covers 256 x (rows per workgroup) rows: taller strips = fewer generations (config 4: two instead of five).  A taller
+// strip's column-sorted stream is also denser (1954-row strips: a mean gap of 160 columns, 4883-row strips: 64), so adjacent lanes
+// of one gather instruction share a line of x -- one L2 request -- more often: worth a few per cent by itself (the column-parts
+// experiment, profiles/r06_colsweep_column_parts.txt).  The 16-bit row word spends 13 bits on the row (turns capped at 7), the
+// four strips of a workgroup may fill the CU's LDS (kSweepMaxRb rows = 160 KB of sums), and config 4 whole runs
+// 1.98 -> 1.73-1.86 ms as 2 generations of 256 x 19532 rows.
 constexpr int kSweepMaxRb = 20480;
 double sweep_rate(int rb)
 {
