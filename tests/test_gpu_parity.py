@@ -1295,7 +1295,7 @@ def test_bench_script_runs_small(torch, tmp_path):
     assert cpu["gpu_rows_bit_identical_to_serial"] > 0.98 and r["y_equals_tiled_reference_y"] is True
     assert "substitute" in j["config"]["workload"]
     # every figure a record needs is a flat scalar of `roofline`
-    for key in ("frac_tjds", "frac_tjds_colmajor", "frac_survey_random_model", "frac_config4", "frac_pwt_csr", "frac_pwt_tjds",
+    for key in ("frac", "traffic", "frac_tjds", "frac_tjds_colmajor", "frac_survey_random_model", "frac_config4", "frac_pwt_csr", "frac_pwt_tjds",
                 "ms_tjds", "ms_survey_random_model", "ms_config4",
                 "config4_t1_ms", "config4_tN_step_ms", "config4_tN_step_after_ms", "config4_tN_products_only_ms",
                 "config4_speedup_overlapped", "config4_speedup_after", "config4_speedup_products_only", "config4_chunks_chosen",
