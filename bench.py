@@ -78,6 +78,8 @@ def scalars(d, keep=()):
             continue
         if isinstance(v, str) and len(v) > STRING_LIMIT:
             v = v[:STRING_LIMIT - 3] + "..."
+        if isinstance(v, float) and (v != v or v in (float("inf"), float("-inf"))):
+            v = None        # (NaN / Infinity are not JSON: a strict parser would lose the whole line over one of them)
         if isinstance(v, float) and v == v and abs(v) not in (0.0, float("inf")) and len(repr(v)) > 12:
             v = float("%.6g" % v)
         out[k] = v
@@ -94,7 +96,7 @@ PROTECTED = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "
 
 def compact_line(state):
     """The one stdout line: contract keys, `roofline` / `cpu_baseline` / `config` as flat scalars, nothing nested below them."""
-    line = dict(state["head"])
+    line = scalars(state["head"])
     line["config"] = scalars(state["config"])
     roof = scalars(state["roofline"])
     for leg, err in state["errors"].items():
@@ -107,14 +109,14 @@ def compact_line(state):
     line["roofline"] = roof
     line["cpu_baseline"] = scalars(state["cpu"]) if state["cpu"] else None
     line["detail"] = os.path.basename(state["detail_path"]) if state.get("detail_written") else None
-    text = json.dumps(line)
+    text = json.dumps(line, allow_nan=False)
     for prefix in DROP_ORDER:
         if len(text) <= LINE_LIMIT:
             break
         for k in [k for k in roof if k.startswith(prefix) and k not in PROTECTED]:
             del roof[k]
         roof["dropped_for_length"] = True
-        text = json.dumps(line)
+        text = json.dumps(line, allow_nan=False)
     return text
 
 

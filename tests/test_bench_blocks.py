@@ -200,8 +200,9 @@ def test_compact_line_is_short_flat_and_keeps_the_contract():
 
     flat = {"frac_tjds": 0.61, "frac_survey_random_model": 0.33, "frac_config4": 0.26, "config4_t1_ms": 1.96, "config4_speedup_overlapped": 5.5,
             "rccl_ranks": 8}
-    text = bench.compact_line(_state(**flat))
-    j = json.loads(text)
+    text = bench.compact_line(_state(**flat, frac_broken=float("nan"), ms_broken=float("inf")))
+    j = json.loads(text, parse_constant=lambda c: pytest.fail("%s on the line: not JSON" % c))
+    assert j["roofline"]["frac_broken"] is None and j["roofline"]["ms_broken"] is None
     assert len(text) < 3000 and "\n" not in text
     for obj in (j["roofline"], j["cpu_baseline"], j["config"]):
         assert all(not isinstance(v, (dict, list)) for v in obj.values())
