@@ -317,6 +317,8 @@ int build_sweep_plan(smvp_csr *h, int want)
         h->sweep_parts >>= 1;  // (a chosen height may leave room for fewer parts than asked)
     const int strip_rows = h->sweep_rb * h->sweep_parts / smvp::kSweepWaves;
     h->sweep_g = smvp::sweep_chunks_in_flight(strip_rows);
+    if (const hipError_t pe = smvp::prepare_csr_colsweep(); pe != hipSuccess)
+        return smvp::fail(SMVP_ERR_HIP, "the column sweep cannot have its LDS: %s", hipGetErrorString(pe));
     const int nstrips = (h->rows + strip_rows - 1) / strip_rows;
     const size_t n = (size_t)std::max(h->nnz, 4);
     if (hipMalloc((void **)&h->d_sweep_ptr, ((size_t)nstrips * h->sweep_parts + 2) * sizeof(long long)) != hipSuccess ||

@@ -1588,6 +1588,20 @@ int sweep_chunks_in_flight(int strip_rows)
     return env_g == 1 || env_g == 2 || env_g == 4 ? env_g : (strip_rows >= 768 ? 2 : 1);
 }
 
+// Strips taller than 2048 rows need more dynamic LDS (up to the CU's 160 KB) than a kernel gets unasked: asked for here, for every
+// form of the kernel, on the CURRENT device -- once per plan build (the engine), never on a launch path; always the same
+// maximum, so that plans of different heights on one device cannot take it from one another.
+constexpr size_t kSweepMaxLds = 160u * 1024;
+hipError_t prepare_csr_colsweep()
+{
+    for (const void *f : {(const void *)csr_colsweep<1>, (const void *)csr_colsweep<2>, (const void *)csr_colsweep<4>}) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweepMaxLds);
+        if (e != hipSuccess)
+            return e;
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, const double *e_val, const unsigned short *e_row,
                                const double *x, double *y, int rows, int strip_rows, int parts, int per_launch, int g, hipStream_t stream)
 {
@@ -1600,13 +1614,8 @@ hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, con
     const size_t lds = sizeof(double) * (size_t)strip_rows * kSweepWaves;
     if (per_launch <= 0)
         per_launch = nwg;
-    if (lds > 64u * 1024) {  // strips taller than 2048 rows: more dynamic LDS than a kernel gets unasked
-        const hipError_t e = g == 4   ? hipFuncSetAttribute((const void *)csr_colsweep<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                             : g == 2 ? hipFuncSetAttribute((const void *)csr_colsweep<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                                      : hipFuncSetAttribute((const void *)csr_colsweep<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess)
-            return e;
-    }
+    if (lds > kSweepMaxLds)
+        return hipErrorInvalidValue;  // (strips of more than 5120 rows; up to there prepare_csr_colsweep has asked for the LDS)
     for (int first = 0; first < nwg; first += per_launch) {
         const unsigned grid = (unsigned)(nwg - first < per_launch ? nwg - first : per_launch);
 #define SMVP_SWEEP(GG)                                                                                                   \
