@@ -554,6 +554,9 @@ def c_layer_in_child(args, ngpus, steps, rank):
 
 
 
+L2_GATHER_CEILING_G = 189.0     # G random 8-byte gathers per second out of the L2s, measured (profiles/r01_gather_microbench.txt)
+
+
 def flat_keys(roof, others, extra, world, dist_info):
     """The figures a record needs as FLAT SCALARS inside `roofline` -- the compact line carries nothing nested (bench.py
     compact_line), so the other kernels' fractions, traffic over algorithmic bytes, config 4's t1 / tN / speed-up keys, the C
@@ -580,6 +583,12 @@ def flat_keys(roof, others, extra, world, dist_info):
     for k in ("t1_ms", "tN_step_ms", "tN_step_after_ms", "tN_products_only_ms", "speedup_overlapped", "speedup_after",
               "speedup_products_only", "chunks_chosen"):
         put("config4_" + k, c4.get(k))
+    # config 4 is bound by random 8-byte gathers that hit the L2, not by HBM bytes: the rate beside the chip's ceiling for such gathers
+    # (189 G/s: tools/gather_bench.hip, a 4 MB table, 8 gathers in flight per lane -- profiles/r01_gather_microbench.txt)
+    xg = (extra.get("config4") or {}).get("x_gathers_per_second_G_per_gpu")
+    if xg:
+        put("config4_G_gathers_per_s_per_gpu", xg, 1)
+        put("config4_frac_of_l2_gather_ceiling", float(xg) / L2_GATHER_CEILING_G)
     e8 = c4.get("eighth_of_n8") or {}
     for c, ms in ((e8.get("inputs") or {}).get("product_ms_by_chunks") or {}).items():
         put("config4_eighth_ms_%schunk" % c, ms)

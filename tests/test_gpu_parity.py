@@ -1299,7 +1299,8 @@ def test_bench_script_runs_small(torch, tmp_path):
                 "ms_tjds", "ms_survey_random_model", "ms_config4",
                 "config4_t1_ms", "config4_tN_step_ms", "config4_tN_step_after_ms", "config4_tN_products_only_ms",
                 "config4_speedup_overlapped", "config4_speedup_after", "config4_speedup_products_only", "config4_chunks_chosen",
-                "config4_eighth_ms_1chunk", "config4_eighth_ms_2chunk", "config4_eighth_ms_4chunk",
+                "config4_eighth_ms_1chunk", "config4_eighth_ms_2chunk", "config4_eighth_ms_4chunk", "config4_G_gathers_per_s_per_gpu",
+                "config4_frac_of_l2_gather_ceiling",
                 "config4_c_layer_products_only_ms_1chunk", "config4_c_layer_overlapped_ms_1chunk", "config4_c_layer_after_ms_4chunk",
                 "exchange_rccl_ms", "exchange_copies_ms", "exchange_direct_ms", "c_layer_exchange_chosen",
                 "memplus_csr_us", "memplus_tjds_us", "memplus_csr_loop_wall_us", "pwt_csr_us", "config5_csr_us", "config5_both_us",
