@@ -554,7 +554,7 @@ def c_layer_in_child(args, ngpus, steps, rank):
 
 
 
-L2_GATHER_CEILING_G = 189.0     # G random 8-byte gathers per second out of the L2s, measured (profiles/r01_gather_microbench.txt)
+L2_GATHER_CEILING_G = 246.0     # G random 8-byte gathers per second that HIT the L2 (a 1 MB table, 16 in flight per lane; 190 with a 4 MB table that only just fits): profiles/r06_gather_ceiling.txt
 
 
 def flat_keys(roof, others, extra, world, dist_info):
@@ -584,7 +584,7 @@ def flat_keys(roof, others, extra, world, dist_info):
               "speedup_products_only", "chunks_chosen"):
         put("config4_" + k, c4.get(k))
     # config 4 is bound by random 8-byte gathers that hit the L2, not by HBM bytes: the rate beside the chip's ceiling for such gathers
-    # (189 G/s: tools/gather_bench.hip, a 4 MB table, 8 gathers in flight per lane -- profiles/r01_gather_microbench.txt)
+    # (tools/gather_ceiling.hip -- profiles/r06_gather_ceiling.txt)
     xg = (extra.get("config4") or {}).get("x_gathers_per_second_G_per_gpu")
     if xg:
         put("config4_G_gathers_per_s_per_gpu", xg, 1)
