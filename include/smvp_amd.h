@@ -376,6 +376,9 @@ int smvp_sharded_layout(const smvp_sharded_t *h, int *chunks, int *bounds, int *
 void smvp_sharded_destroy(smvp_sharded_t *h);
 
 #define SMVP_CSR_SWEEP_PARTS(rows_per_block, parts) ((rows_per_block) | (((parts) == 4 ? 2 : (parts) == 2 ? 1 : 0) << 24))
+/* for experiments: the same with the 256-entry chunks a wavefront keeps in flight forced to 1, 2 or 4 (0 = the library's rule) */
+#define SMVP_CSR_SWEEP_PARAM(rows_per_block, parts, chunks) \
+    (SMVP_CSR_SWEEP_PARTS(rows_per_block, parts) | (((chunks) == 4 ? 3 : (chunks) == 2 ? 2 : (chunks) == 1 ? 1 : 0) << 26))
 
 /* ------------------------------------------------ reference-shaped entry points */
 typedef struct smvp_run_opts {

@@ -294,13 +294,16 @@ void choose_sweep_shape(int rows, int cols, int nnz, int want_rb, int *rb, int *
 // (one rank's eighth of config 4: 256 workgroups x 4884 rows = four strips of 1221) gets the denser streams of a tall strip
 // (one strip of 4884) -- and a row's sum is its partial sums added part by part: reproducible, inside the rounding bound, no
 // longer the serial loop's bits.  Never chosen by AUTO (which keeps the serial order); SMVP_CSR_SWEEP_PARTS(rb, parts) asks for it.
-constexpr int kSweepPartsShift = 24;
+// Above the parts (bits 26-27): chunks in flight per wavefront for experiments -- 0 = the rule (sweep_chunks_in_flight), 1 / 2 / 3 = one /
+// two / four (what the environment switch SMVP_SWEEP_G used to say; tools/exp_colsweep.py --g).
+constexpr int kSweepPartsShift = 24, kSweepChunksShift = 26;
 inline int sweep_param_rb(int param) { return param & ((1 << kSweepPartsShift) - 1); }
 inline int sweep_param_parts(int param) { return 1 << ((param >> kSweepPartsShift) & 3); }
+inline int sweep_param_chunks(int param) { const int c = (param >> kSweepChunksShift) & 3; return c == 3 ? 4 : c; }
 bool sweep_param_ok(int param)
 {
     const int rb = sweep_param_rb(param), parts = sweep_param_parts(param);
-    if (param < 0 || (param >> kSweepPartsShift) > 2)
+    if (param < 0 || (param >> (kSweepChunksShift + 2)) != 0 || ((param >> kSweepPartsShift) & 3) > 2)
         return false;
     if (rb == 0)
         return true;  // (height chosen; the parts are honoured where the chosen height leaves room for them)
@@ -316,7 +319,7 @@ int build_sweep_plan(smvp_csr *h, int want)
     while (h->sweep_parts > 1 && (long long)h->sweep_rb * h->sweep_parts > kSweepMaxRb)
         h->sweep_parts >>= 1;  // (a chosen height may leave room for fewer parts than asked)
     const int strip_rows = h->sweep_rb * h->sweep_parts / smvp::kSweepWaves;
-    h->sweep_g = smvp::sweep_chunks_in_flight(strip_rows);
+    h->sweep_g = smvp::sweep_chunks_in_flight(strip_rows, sweep_param_chunks(want));
     if (const hipError_t pe = smvp::prepare_csr_colsweep(); pe != hipSuccess)
         return smvp::fail(SMVP_ERR_HIP, "the column sweep cannot have its LDS: %s", hipGetErrorString(pe));
     const int nstrips = (h->rows + strip_rows - 1) / strip_rows;

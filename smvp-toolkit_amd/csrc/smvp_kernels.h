@@ -91,7 +91,7 @@ hipError_t launch_fill(double *p, double v, long long n, hipStream_t stream);
 hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, const double *e_val, const unsigned short *e_row,
                                const double *x, double *y, int rows, int strip_rows, int parts, int per_launch, int g, hipStream_t stream);
 hipError_t prepare_csr_colsweep();  // once per plan build, on the plan's device: the kernel may use up to 160 KB of dynamic LDS
-int sweep_chunks_in_flight(int strip_rows);  // the G of csr_colsweep<G> a strip height runs with (reads SMVP_SWEEP_G: plan time only)
+int sweep_chunks_in_flight(int strip_rows, int asked);  // the G of csr_colsweep<G> a strip height runs with (asked = 1 | 2 | 4 overrides; plan time only)
 // entries of 64 K-entry samples of a CSR matrix that gather from distinct 128-byte lines of x (see csr_line_spread)
 constexpr int kSpreadSpan = 64 * 1024;
 hipError_t launch_csr_line_spread(const int *col_ind, long long nnz, int samples, int *distinct, hipStream_t stream);

@@ -1121,13 +1121,10 @@ hipError_t launch_csr_vector(int lanes_per_row, const int *row_ptr, const int *c
 
 // Tiles per XCD turn for a launch of `ntiles` tiles: kStreamTileGroup, smaller for small matrices so that
 // the grid (rounded up to a multiple of 8 * group) is not mostly empty blocks.
+// (Groups of 1 ... 2048 were swept in rounds 2 and 5 -- within 2 % from 16 on; profiles/HISTORY_r01_r04.md.)
 static int tile_group(int ntiles, int wanted = kStreamTileGroup)
 {
-    static const int env = [] {
-        const char *e = getenv("SMVP_TILE_GROUP");  // development switch
-        return e ? atoi(e) : 0;
-    }();
-    const int g = env >= 1 ? env : wanted;
+    const int g = wanted;
     const int fit = ntiles / 64;
     return fit < 1 ? 1 : (fit < g ? fit : g);
 }
@@ -1579,13 +1576,11 @@ __global__ __launch_bounds__(kSweepBlock) void csr_colsweep(
 // short).  Measured (MI355X, config 4's columns; ms for G = 1 / 2; profiles/r05_colsweep_heights.txt): strips of 2048 rows
 // 2.55 / 2.25 (10 M rows), 0.497 / 0.444 (1.25 M rows); 1221 rows 0.315 / 0.287 (1.25 M), 0.632 / 0.575 (2.5 M); 814 rows
 // 0.648 / 0.636; 611 rows 0.328 / 0.373; 512 rows 0.413 / 0.468; 407 rows 0.348 / 0.459 -- two from about 800 rows on.
-// SMVP_SWEEP_G=1|2|4 overrides (development switch).  Asked once per plan build (the engine keeps the answer in the
-// handle), never on a launch path.
-int sweep_chunks_in_flight(int strip_rows)
+// `asked` = 1 | 2 | 4 overrides (SMVP_CSR_SWEEP_PARAM's third field: experiments); 0 = the rule.  Asked once per plan build
+// (the engine keeps the answer in the handle), never on a launch path.
+int sweep_chunks_in_flight(int strip_rows, int asked)
 {
-    const char *env = getenv("SMVP_SWEEP_G");
-    const int env_g = env ? atoi(env) : 0;
-    return env_g == 1 || env_g == 2 || env_g == 4 ? env_g : (strip_rows >= 768 ? 2 : 1);
+    return asked == 1 || asked == 2 || asked == 4 ? asked : (strip_rows >= 768 ? 2 : 1);
 }
 
 // Strips taller than 2048 rows need more dynamic LDS (up to the CU's 160 KB) than a kernel gets unasked: asked for here, for every

@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--local-rows", type=int, default=0)
     ap.add_argument("--per-row", type=int, default=32)
     ap.add_argument("--rb", default="0")
-    ap.add_argument("--g", default="0", help="chunks in flight per wavefront (development switch SMVP_SWEEP_G), comma list")
+    ap.add_argument("--g", default="0", help="chunks in flight per wavefront (0 = the library's rule, 1, 2, 4), comma list")
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--parts", default="1", help="column parts per strip (1, 2, 4), comma list")
     a = ap.parse_args()
@@ -82,8 +82,7 @@ def main():
         y_ref = y_ref - y_near
         nnz = int(far.sum())
     for rb, g, parts in [(int(s), g, int(p)) for s in a.rb.split(",") for p in a.parts.split(",") for g in a.g.split(",") * a.repeat]:
-        os.environ["SMVP_SWEEP_G"] = g
-        S.set_kernel(sm.CSR_KERNEL_COLSWEEP, sm.sweep_parts(rb, parts))
+        S.set_kernel(sm.CSR_KERNEL_COLSWEEP, sm.sweep_parts(rb, parts, int(g)))
         y.fill_(float("nan"))
         S.spmv(x, y, stream=st)
         torch.cuda.synchronize()
@@ -95,7 +94,7 @@ def main():
         ms = timeit(torch, lambda: S.spmv(x, y, stream=st))
         tot = ms + t_near
         print("colsweep G=%s parts %d rows/block %5d (asked %d): %.4f ms  %.1f G gathers/s  max err %.1e  |  whole product %.4f ms = %.1f %% of 8 TB/s" % (
-            g, 1 << (S.get_kernel()[1] >> 24), S.get_kernel()[1] & 0xffffff, rb, ms, nnz / ms * 1e-6, err, tot, alg / tot * 1e-6 / 80), flush=True)
+            g, 1 << ((S.get_kernel()[1] >> 24) & 3), S.get_kernel()[1] & 0xffffff, rb, ms, nnz / ms * 1e-6, err, tot, alg / tot * 1e-6 / 80), flush=True)
 
 
 if __name__ == "__main__":
