@@ -589,6 +589,12 @@ def flat_keys(roof, others, extra, world, dist_info):
     if xg:
         put("config4_G_gathers_per_s_per_gpu", xg, 1)
         put("config4_frac_of_l2_gather_ceiling", float(xg) / L2_GATHER_CEILING_G)
+    # N > 1: what ONE chunk's all-gather took by chunks per rank, and the local products by chunks per rank (the sweep's measurements)
+    inputs = (c4.get("chunk_choice") or {}).get("inputs") or {}
+    for c, ms in (inputs.get("gather_ms_by_chunks") or {}).items():
+        put("config4_allgather_ms_%schunk" % c, ms)
+    for c, ms in (inputs.get("product_ms_by_chunks") or {}).items():
+        put("config4_products_ms_%schunk" % c, ms)
     e8 = c4.get("eighth_of_n8") or {}
     for c, ms in ((e8.get("inputs") or {}).get("product_ms_by_chunks") or {}).items():
         put("config4_eighth_ms_%schunk" % c, ms)
