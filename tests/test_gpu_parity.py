@@ -326,9 +326,15 @@ def test_colsweep_rows_that_meet_in_a_chunk(torch):
     val = rng.uniform(-1, 1, len(col_ind))
     x = rng.random(cols)
     ref = ob.csr_spmv(row_ptr, col_ind, val, x)
-    for rb in (0, 1024, 8192):
+    for rb in (0, 1024, 8192, 20480):                    # (20480: strips of 5120 rows, the turns capped at 7 since round 6)
         y = gpu_csr(torch, rows, cols, row_ptr, col_ind, val, x, sm.CSR_KERNEL_COLSWEEP, rb)
         assert np.array_equal(y, ref)
+    # column parts: every part's chunks take their own turns; the sums are the serial ones up to the association part by part
+    scale = row_scale(row_ptr, col_ind, val, x)
+    for rb, parts in ((1024, 2), (1024, 4), (5120, 4)):
+        y = gpu_csr(torch, rows, cols, row_ptr, col_ind, val, x, sm.CSR_KERNEL_COLSWEEP, sm.sweep_parts(rb, parts))
+        assert_close(y, ref, scale)
+        assert np.array_equal(y, gpu_csr(torch, rows, cols, row_ptr, col_ind, val, x, sm.CSR_KERNEL_COLSWEEP, sm.sweep_parts(rb, parts)))
 
 
 def test_binned_plan_on_a_row_block_of_a_sharded_matrix(torch):
