@@ -59,6 +59,16 @@ enum {
 };
 const char *smvp_last_error(void);     /* thread-local text of the last failure */
 const char *smvp_version_string(void); /* "0.6.4" */
+/* Plan options for experiments and tests (process-wide; read where a plan or handle is built or a file is parsed, never on a launch
+ * path; value < 0 = back to the library's default).  What earlier rounds read from the environment -- the library reads no
+ * environment variable any more:
+ *   "csr_col16" 0: the CSR tile kernel keeps 32-bit columns           "csr_rowrel" 0: its second phase reads row_ptr
+ *   "binned_near" 1: the binned plan's near part on the tile kernel   "binned_overlap" 0: pass A behind the near part, one stream
+ *   "tjds_index" 0 | 1 | 2: 16-bit position words (default) / 32-bit sorted / 32-bit columns
+ *   "sharded_threads" 1: the sharded layer's issuing threads with one GPU too     "mm_threads" n: the reader's threads (1 = serial)
+ * Unknown names are SMVP_ERR_INVALID. */
+int smvp_set_option(const char *name, int value);
+int smvp_get_option(const char *name, int *value); /* -1 = not set */
 
 /* -------------------------------------------------------------------- types */
 /* One stored entry, 0-based.  Replaces MMRawData, main-cli.c:42-47. */

@@ -233,6 +233,9 @@ static int run_cache(const char *cache, const char *mtx)
 
 int main(int argc, char **argv)
 {
+    // (this test driver, not the library, reads the environment: the reader's thread count for the run)
+    if (const char *e = getenv("SMVP_MM_THREADS"))
+        (void)smvp_set_option("mm_threads", atoi(e));
     if (argc >= 4 && !strcmp(argv[1], "file"))
         run_file(argv[2], argv[3]);
     else if (argc >= 4 && !strcmp(argv[1], "cache"))

@@ -9,6 +9,7 @@ namespace smvp {
 // Records a message for smvp_last_error() and hands back `code`.
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 void clear_error();
+int option(const char *name, int fallback);  // smvp_set_option's value, or `fallback` where it is not set (smvp_error.cpp)
 }  // namespace smvp
 
 // internal, device side (smvp_convert_device.hip): see its definition

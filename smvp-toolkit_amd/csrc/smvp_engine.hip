@@ -459,8 +459,8 @@ void free_stream_plan(smvp_csr *h)
 // handle without offsets.
 void try_column_offsets(smvp_csr *h)
 {
-    const char *env = getenv("SMVP_CSR_COL16");  // development switch: 0 keeps the 32-bit columns
-    if (h->flavor != smvp::kFlavorCsr || h->kernel != SMVP_CSR_KERNEL_STREAM || h->vpt < 4 || h->nnz <= 0 || (env && atoi(env) == 0))
+    if (h->flavor != smvp::kFlavorCsr || h->kernel != SMVP_CSR_KERNEL_STREAM || h->vpt < 4 || h->nnz <= 0 ||
+        smvp::option("csr_col16", 1) == 0)  // (plan option: 0 keeps the 32-bit columns)
         return;
     std::vector<int> tiles;
     if (!h->tile_chosen && h->nnz >= 12 * 1024 * 1024)  // memplus x59 / x118 / x236 (7.4 / 14.9 / 29.8 M entries), 1024- against
@@ -513,7 +513,7 @@ int build_stream_plan(smvp_csr *h)
     if (h->kernel == SMVP_CSR_KERNEL_STREAM) {
         if (int rc = upload(&h->d_tile_next, tile_next))
             return rc;
-        if (h->rows > 0 && getenv("SMVP_CSR_ROWREL") == nullptr) {  // (development switch, plan time: set = keep row_ptr)
+        if (h->rows > 0 && smvp::option("csr_rowrel", 1) != 0) {  // (plan option: 0 = keep row_ptr)
             std::vector<unsigned short> rel((size_t)h->rows);
             for (int b = 0; b < ntiles; ++b) {
                 const long long s0 = (long long)b * tile;
@@ -788,14 +788,11 @@ static int build_binned(smvp_csr *h, int band)
         (void)hipGetLastError();
         return smvp::fail(SMVP_ERR_UNSUPPORTED, "the binned plan needs 154 KB of LDS per workgroup: %s", hipGetErrorString(le));
     }
-    bool window = true;
-    if (const char *e = getenv("SMVP_BINNED_NEAR"))  // development switch (plan time): "tile" keeps the near part on the tile kernel
-        window = strcmp(e, "tile") != 0;
+    const bool window = smvp::option("binned_near", 0) == 0;  // (plan option: 1 keeps the near part on the tile kernel)
     if (int rc = smvp::build_binned_plan(h->d_row_ptr, h->d_col_ind, h->d_val, h->rows, h->cols, h->nnz, band, h->row0, window, &h->bin, nullptr))
         return rc;
     if (h->bin.nw.on) {
-        const char *e = getenv("SMVP_BINNED_OVERLAP");  // development switch (plan time): 0 = pass A behind the near part, one stream
-        if ((!e || atoi(e) != 0) && h->bin.nf > 0) {
+        if (smvp::option("binned_overlap", 1) != 0 && h->bin.nf > 0) {  // (plan option: 0 = pass A behind the near part, one stream)
             HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
@@ -1210,14 +1207,14 @@ void free_row_gather(smvp_tjds *h)
 // position and slot | run hint -- plus the tiles' run tables (kFlavorTjdsH, 4 bytes of index per entry: the default); the same
 // order with the 32-bit position and a 32-bit slot | diagonal word (kFlavorTjdsS, 8 bytes; needs the diagonals to fit 21 bits);
 // or 32-bit permuted columns in row
-// order (kFlavorTjdsK).  SMVP_TJDS_INDEX=half|sorted|k32 selects (development switch; the tests run all three).
+// order (kFlavorTjdsK).  The plan option "tjds_index" = 0 | 1 | 2 selects (smvp_set_option; the tests run all three).
 int row_gather_index(const smvp_tjds *h)
 {
-    const char *e = getenv("SMVP_TJDS_INDEX");
+    const int e = smvp::option("tjds_index", 0);
     const bool fits_sorted = ((long long)std::max(h->num_diag - 1, 0) >> (32 - smvp::kSlotBits)) == 0;
-    if (e && !strcmp(e, "k32"))
+    if (e == 2)
         return smvp::kFlavorTjdsK;
-    if (e && !strcmp(e, "sorted") && fits_sorted)
+    if (e == 1 && fits_sorted)
         return smvp::kFlavorTjdsS;
     return smvp::kFlavorTjdsH;
 }

@@ -382,11 +382,12 @@ extern "C" int smvp_mm_read_coo_entries(FILE *f, const smvp_mm_typecode matcode,
     }
     const char *p = buf.data(), *end = buf.data() + buf.size() - 1;
     const bool pattern = (matcode[2] == 'P');
-    // SMVP_MM_THREADS overrides the thread count (1 = always serial); small files are not worth the threads
+    // the plan option "mm_threads" overrides the thread count (1 = always serial); small files are not worth the threads
     int threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (const char *e = getenv("SMVP_MM_THREADS"))
-        threads = std::max(1, atoi(e));
-    const bool big = (end - p) >= (8 << 20) || getenv("SMVP_MM_THREADS");
+    const int asked = smvp::option("mm_threads", 0);
+    if (asked > 0)
+        threads = asked;
+    const bool big = (end - p) >= (8 << 20) || asked > 0;
     if (threads > 1 && big && nnz > 0 && parse_entries_parallel(p, end, pattern, nnz, out, threads))
         return SMVP_OK;
     return parse_entries_serial(p, end, pattern, nnz, out);

@@ -772,11 +772,7 @@ namespace {
 int run_job(smvp_sharded *h, int allgather, int timed, bool skip_products)
 {
     const size_t n = (size_t)h->n;
-    static const bool always_threads = [] {
-        const char *e = getenv("SMVP_SHARDED_THREADS");  // development switch: the issuing threads with one GPU too
-        return e && atoi(e) != 0;
-    }();
-    if (n == 1 && !always_threads) {
+    if (n == 1 && h->issuer.empty() && smvp::option("sharded_threads", 0) == 0) {  // (plan option: 1 = the issuing threads with one GPU too)
         DeviceScope keep;
         const int rc = issue_product(h, 0, allgather, timed, skip_products);
         if (rc != SMVP_OK && allgather) {

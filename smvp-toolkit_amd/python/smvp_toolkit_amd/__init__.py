@@ -29,6 +29,33 @@ TIMING_AUTO, TIMING_EVENTS, TIMING_DEVICE, TIMING_DEVICE_GRAPH = 0, 1, 2, 3
 COO_DTYPE = np.dtype([("row", "<i4"), ("col", "<i4"), ("val", "<f8")], align=True)
 
 
+def set_option(name, value):
+    """smvp_set_option: a plan option for experiments and tests (include/smvp_amd.h); value < 0 or None = the library's default."""
+    _check(lib().smvp_set_option(name.encode(), -1 if value is None else int(value)), "smvp_set_option")
+
+
+def get_option(name):
+    v = C.c_int()
+    _check(lib().smvp_get_option(name.encode(), C.byref(v)), "smvp_get_option")
+    return v.value
+
+
+class option:
+    """with sm.option("csr_col16", 0): ...  -- sets a plan option for the block and restores what was there."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
+
+
 def sweep_parts(rows_per_block, parts, chunks=0):
     """SMVP_CSR_SWEEP_PARTS / SMVP_CSR_SWEEP_PARAM: the column sweep's kernel parameter with 2 or 4 column parts per strip and,
     for experiments, the chunks a wavefront keeps in flight forced to 1, 2 or 4 (include/smvp_amd.h)."""
@@ -75,7 +102,7 @@ _lib = None
 
 # every symbol include/smvp_amd.h declares; tests check that all of them resolve
 EXPORTS = [
-    "smvp_last_error", "smvp_version_string",
+    "smvp_last_error", "smvp_version_string", "smvp_set_option", "smvp_get_option",
     "smvp_mm_read_banner", "smvp_mm_read_mtx_crd_size", "smvp_mm_read_coo_entries",
     "smvp_mm_read_header_path", "smvp_mm_read_coo_path", "smvp_mm_expanded_count", "smvp_mm_expand_symmetric",
     "smvp_cache_write_csr", "smvp_cache_read_header", "smvp_cache_read_csr", "smvp_coo_from_csr",
@@ -104,6 +131,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.smvp_last_error.restype = C.c_char_p
         L.smvp_version_string.restype = C.c_char_p
+        L.smvp_set_option.argtypes = [C.c_char_p, C.c_int]
+        L.smvp_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
         vp, ci = C.c_void_p, C.c_int
         L.smvp_csr_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, vp, vp, vp, ci, vp]
         L.smvp_csr_create_block.argtypes = [C.POINTER(vp), ci, ci, ci, ci, vp, vp, vp, ci, vp, C.c_longlong]

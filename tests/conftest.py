@@ -27,6 +27,19 @@ def native_builds():
     yield
 
 
+PLAN_OPTIONS = ("csr_col16", "csr_rowrel", "binned_near", "binned_overlap", "tjds_index", "sharded_threads", "mm_threads")
+
+
+@pytest.fixture(autouse=True)
+def plan_options_back_to_default():
+    """Plan options (smvp_set_option) are process-wide: whatever a test sets is taken back after it."""
+    yield
+    import smvp_toolkit_amd as sm
+
+    for name in PLAN_OPTIONS:
+        sm.set_option(name, None)
+
+
 SAMPLES = ["ibm32.mtx", "curtis54.mtx", "pdp08-pg4.mtx", "memplus.mtx", "pwt.mtx"]
 
 # committed reference reports: matrix -> (CSR report stamp, TJDS report stamp or None)

@@ -169,24 +169,24 @@ def test_csr_16_bit_column_offsets(torch):
         A.set_kernel(sm.CSR_KERNEL_STREAM, 256)                     # 256-entry tiles always read col_ind
         assert A.describe()[0] == "csr_stream_owner<1, 0, false>"
         A.close()
-    # the development switch: same bits without the offsets
+    # the plan option (smvp_set_option): same bits without the offsets
     m, n, coo = load("memplus.mtx")
     row_ptr, col_ind, val = sm.csr_from_coo(coo, m)
     x = rng.random(n)
     got = []
-    for env in ("1", "0"):
-        os.environ["SMVP_CSR_COL16"] = env
-        try:
+    for col16 in (1, 0):
+        with sm.option("csr_col16", col16):
             A = sm.CsrMatrix(m, n, row_ptr, col_ind, val)
             A.set_kernel(sm.CSR_KERNEL_STREAM, 1024)
-            assert A.describe()[0] == "csr_stream_owner<4, %d, false>" % (5 if env == "1" else 0)
+            assert A.describe()[0] == "csr_stream_owner<4, %d, false>" % (5 if col16 else 0)
             dy = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
             A.spmv(dev(torch, x), dy)
             torch.cuda.synchronize()
             got.append(dy.cpu().numpy())
             A.close()
-        finally:
-            del os.environ["SMVP_CSR_COL16"]
+    assert sm.get_option("csr_col16") == -1
+    with pytest.raises(sm.SmvpError):
+        sm.set_option("no_such_option", 1)
     assert np.array_equal(got[0], got[1])
     # round 5: tiles of 1024 / 2048 entries read every row's start as a 16-bit offset from the tile's first entry instead of
     # row_ptr (2 instead of 4 bytes per row).  Same bits with the development switch that keeps row_ptr -- CSR and TJDS, rows
@@ -208,9 +208,7 @@ def test_csr_16_bit_column_offsets(torch):
     coo2 = sm.make_coo(np.repeat(np.arange(len(lens)), lens), ci2, v2)
     got = {}
     for env in (None, "0"):
-        if env is not None:
-            os.environ["SMVP_CSR_ROWREL"] = env
-        try:
+        with sm.option("csr_rowrel", None if env is None else 0):
             for tile in (1024, 2048):
                 A = sm.CsrMatrix(len(lens), 5000, rp2, ci2, v2)
                 A.set_kernel(sm.CSR_KERNEL_STREAM, tile)
@@ -229,8 +227,6 @@ def test_csr_16_bit_column_offsets(torch):
                 got["tjds", tile, env] = dy.cpu().numpy()
                 assert_close(got["tjds", tile, env], ref2, sc2)
                 T.close()
-        finally:
-            os.environ.pop("SMVP_CSR_ROWREL", None)
     for fmt in ("csr", "tjds"):
         for tile in (1024, 2048):
             assert np.array_equal(got[fmt, tile, None], got[fmt, tile, "0"])
@@ -389,12 +385,12 @@ def test_binned_plan_on_a_row_block_of_a_sharded_matrix(torch):
 
 
 @pytest.mark.parametrize("near", ["window", "tile"])
-def test_binned_plan_on_the_random_model(torch, monkeypatch, near):
+def test_binned_plan_on_the_random_model(torch, near):
     """SURVEY 8(d)'s memplus-shaped random model (2^22 rows here): AUTO picks the binned plan -- near part with a row
-    block's window of x in LDS (or, SMVP_BINNED_NEAR=tile at plan time, on the tile kernel), far part through the
+    block's window of x in LDS (or, plan option "binned_near" = 1, on the tile kernel), far part through the
     LDS-binned passes; the result is within the normwise bound of the serial loop, the same bits from run to run, equal
     to the serial loop's bits on every short row without far entries; the plan's size is what smvp_csr_plan_info says."""
-    monkeypatch.setenv("SMVP_BINNED_NEAR", near)
+    sm.set_option("binned_near", 1 if near == "tile" else 0)        # (conftest.py resets the plan options after every test)
     rows = 1 << 22
     row_ptr, col_ind, val = sm.synth_csr(sm.SYNTH_MEMPLUS_SHAPED, 12345, rows, rows)
     x = sm.vector_random(rows)
@@ -483,7 +479,7 @@ def test_binned_plan_corner_structures(torch):
     assert_close(y, ob.csr_spmv(row_ptr, col_ind, val, x), row_scale(row_ptr, col_ind, val, x))
 
 
-def test_binned_near_engines(torch, monkeypatch):
+def test_binned_near_engines(torch):
     """The near part's two engines -- the window plan (a row block's window of x in LDS, rows sorted by length, long rows
     summed by a wavefront) and the tile kernel -- against the oracle on structures that stress the window plan: several
     row blocks with a ragged last one, rows of 0 ... 16 (lanes of a slice), 17 ... 300 (slices of their own) entries, empty
@@ -523,8 +519,8 @@ def test_binned_near_engines(torch, monkeypatch):
         scale = row_scale(row_ptr, col_ind, val, x)
         got = {}
         for near in ("window", "window, one stream", "tile"):
-            monkeypatch.setenv("SMVP_BINNED_NEAR", near.split(",")[0])
-            monkeypatch.setenv("SMVP_BINNED_OVERLAP", "0" if "one stream" in near else "1")   # pass A beside the near part, or behind it
+            sm.set_option("binned_near", 1 if near.startswith("tile") else 0)
+            sm.set_option("binned_overlap", 0 if "one stream" in near else 1)   # pass A beside the near part, or behind it
             A = sm.CsrMatrix(rows, cols, row_ptr, col_ind, val)
             A.set_kernel(sm.CSR_KERNEL_BINNED, band)
             name = A.describe()[0]
@@ -545,7 +541,7 @@ def test_binned_near_engines(torch, monkeypatch):
         assert np.array_equal(got["window"][short], got["tile"][short])     # both sum a short row left to right
         assert np.array_equal(got["window"], got["window, one stream"])     # the same kernels, side by side or one after the other
     # more long rows in a block than the window plan takes: it stays on the tile kernel
-    monkeypatch.setenv("SMVP_BINNED_NEAR", "window")
+    sm.set_option("binned_near", 0)
     rows = 8192
     lens = np.full(rows, 40)
     row_ptr, col_ind, val = csr_from_lengths(rng, lens.tolist(), rows)
@@ -674,15 +670,8 @@ TJDS_FLAVORS = {"half": (4,), "sorted": (3,), "k32": (2,)}
 
 def tjds_gather_matrix(t, index, tile):
     """TjdsMatrix on the one-kernel product with the given stream form and tile size (0 = the plan's own choice)."""
-    old = os.environ.get("SMVP_TJDS_INDEX")
-    os.environ["SMVP_TJDS_INDEX"] = index
-    try:
+    with sm.option("tjds_index", {"half": 0, "sorted": 1, "k32": 2}[index]):
         T = sm.TjdsMatrix(t)
-    finally:
-        if old is None:
-            del os.environ["SMVP_TJDS_INDEX"]
-        else:
-            os.environ["SMVP_TJDS_INDEX"] = old
     if tile:
         T.set_tile(tile)
     name = T.describe()[0]
@@ -1841,7 +1830,7 @@ def test_cli_exchange_and_timing_flags(torch, tmp_path):
 
 def test_sharded_issuing_thread_machinery_on_one_gpu(torch, tmp_path):
     """With several GPUs every GPU's launches and collectives are issued by its own thread (woken per product, joined at
-    destroy).  SMVP_SHARDED_THREADS=1 runs that machinery with the one GPU of this box: many products, both exchange
+    destroy).  The plan option "sharded_threads" = 1 runs that machinery with the one GPU of this box: many products, both exchange
     forms, power iteration, an early destroy -- same results as the caller's-thread path."""
     import sys
 
@@ -1852,6 +1841,7 @@ import smvp_toolkit_amd as sm, oracle_binding as ob
 tc, m, n, coo = sm.mm_read_coo(ob.fixture_path("memplus.mtx"))
 rp, ci, v = sm.csr_from_coo(coo, m)
 ref = ob.csr_spmv(rp, ci, v, np.ones(n))
+sm.set_option("sharded_threads", 1)
 for fmt in ("csr", "tjds"):
     S = sm.ShardedMatrix(fmt, 1, m, n, coo=coo, csr=(rp, ci, v), chunks=4)
     S.set_x(None)
@@ -1872,8 +1862,7 @@ y, ms, st = sm.csr_compute(coo, m, n, iters=20)
 assert np.allclose(y, ref, rtol=1e-12, atol=1e-12)
 print("threads ok")
 """ % (os.path.join(os.path.dirname(sm.LIB_PATH), "..", "python"), os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SMVP_SHARDED_THREADS="1")
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "threads ok" in p.stdout, p.stdout + p.stderr
 
 

@@ -307,7 +307,7 @@ def test_parallel_tokeniser_equals_serial(tmp_path, monkeypatch, threads, patter
     v = rng.uniform(-1e3, 1e3, n) * 10.0 ** rng.integers(-20, 20, n)
     p = str(tmp_path / "m.mtx")
     _write_mtx(p, 5000, 7000, r, c, v, pattern=pattern, sep="\n" if not pattern else "  \t\n ")
-    monkeypatch.setenv("SMVP_MM_THREADS", threads)
+    sm.set_option("mm_threads", int(threads))        # (conftest.py resets the plan options after every test)
     tc, m, k, coo = sm.mm_read_coo(p)
     assert (m, k, len(coo)) == (5000, 7000, n)
     assert np.array_equal(coo["row"], r) and np.array_equal(coo["col"], c)
@@ -337,7 +337,7 @@ def test_parallel_tokeniser_number_spellings(tmp_path, monkeypatch):
             f.write("%s%d \t+%d %s\r\n" % ("000" if a % 3 == 0 else "", a, b, t))
     want = np.array([float.fromhex(t) if "0x" in t else float(t) for t in toks])
     for threads in ("1", "5"):
-        monkeypatch.setenv("SMVP_MM_THREADS", threads)
+        sm.set_option("mm_threads", int(threads))
         tc, m, k, coo = sm.mm_read_coo(str(p))
         assert np.array_equal(coo["row"], r - 1) and np.array_equal(coo["col"], c - 1)
         got = coo["val"]
@@ -345,7 +345,7 @@ def test_parallel_tokeniser_number_spellings(tmp_path, monkeypatch):
 
 
 def test_parallel_tokeniser_on_sample_and_fallbacks(tmp_path, monkeypatch):
-    monkeypatch.setenv("SMVP_MM_THREADS", "8")
+    sm.set_option("mm_threads", 8)
     tc, m, n, coo = sm.mm_read_coo(ob.fixture_path("memplus.mtx"))
     rc, tc2, m2, n2, coo2 = ob.mm_read_coo(ob.fixture_path("memplus.mtx"))
     assert coo.tobytes() == coo2.tobytes()

@@ -93,7 +93,7 @@ def main():
         for var in a.variants.split(","):
             parts = var.split(":")
             mode = modes[parts[0]]
-            os.environ["SMVP_TJDS_INDEX"] = parts[1] if len(parts) > 1 else "half"
+            sm.set_option("tjds_index", {"half": 0, "sorted": 1, "k32": 2}[parts[1] if len(parts) > 1 else "half"])
             t0 = time.perf_counter()
             T = sm.TjdsMatrix(tj)          # default plan is built here ...
             T.set_mode(mode)               # ... and the variant's own one here

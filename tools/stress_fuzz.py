@@ -104,7 +104,7 @@ def main():
         coo = coo[np.random.default_rng(seed).permutation(len(coo))]
         t = sm.tjds_from_coo(coo, rows, cols)
         for index in ("half", "sorted", "k32"):
-            os.environ["SMVP_TJDS_INDEX"] = index
+            sm.set_option("tjds_index", {"half": 0, "sorted": 1, "k32": 2}[index])
             T = sm.TjdsMatrix(t)
             T.set_x(dx)
             for tile in (0, 256, 1024, 2048):
@@ -133,7 +133,7 @@ def main():
                 torch.cuda.synchronize()
                 check(dy.cpu().numpy()[:rows], "tjds mode %d" % mode)
             T.close()
-        del os.environ["SMVP_TJDS_INDEX"]
+        sm.set_option("tjds_index", None)
         y, _, _ = sm.csr_compute(coo, rows, cols, iters=3, x=x)        # (device-timed: the repeating kernel, three products in one launch)
         check(y, "csr_compute")
         y, _, _ = sm.tjds_compute(coo, rows, cols, iters=3, x=x, device_convert=True)

@@ -50,13 +50,14 @@ def main():
         dx = torch.from_numpy(x).cuda()
         d = [torch.from_numpy(t).cuda() for t in (rp, ci, v)]
         ys, names = [], []
-        for env in ({}, {"SMVP_CSR_COL16": "0"}):
-            os.environ.update(env)
+        for env in ({}, {"csr_col16": 0}):
+            for k, val_ in env.items():
+                sm.set_option(k, val_)
             A = sm.CsrMatrix(rows, cols, *d)
             if env:
                 A.set_kernel(sm.CSR_KERNEL_STREAM, 0)
             for k in env:
-                del os.environ[k]
+                sm.set_option(k, None)
             y = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
             A.spmv(dx, y)
             torch.cuda.synchronize()
@@ -93,9 +94,9 @@ def main():
         del d_coo
         yt = []
         for index, cache in (("half", 2), ("sorted", 4), ("half", 0)):
-            os.environ["SMVP_TJDS_INDEX"] = index
+            sm.set_option("tjds_index", {"half": 0, "sorted": 1, "k32": 2}[index])
             T = sm.TjdsMatrix(tj)
-            del os.environ["SMVP_TJDS_INDEX"]
+            sm.set_option("tjds_index", None)
             T.set_value_cache(cache)
             T.set_x(dx)
             y = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")

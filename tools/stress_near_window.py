@@ -70,7 +70,7 @@ def main():
         dx = torch.from_numpy(x).cuda()
         got = {}
         for near in ("window", "tile"):
-            os.environ["SMVP_BINNED_NEAR"] = near
+            sm.set_option("binned_near", 1 if near == "tile" else 0)
             A = sm.CsrMatrix(rows, cols, row_ptr, col_ind, val)
             A.set_kernel(sm.CSR_KERNEL_BINNED, band)
             name = A.describe()[0]
