@@ -31,10 +31,9 @@
 //
 // The plan -- near arrays, both streams, the bins -- is built on the device (rocPRIM sorts and scans: set-up work).
 #include "smvp_common.h"
+#include "smvp_prim.h"
 #include "smvp_kernels.h"
 
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <atomic>
@@ -647,20 +646,20 @@ __global__ __launch_bounds__(256) void bin_far_rows_packed(const int *__restrict
 int scan_exclusive(const int *in, int *out, size_t n, Scratch &sc, hipStream_t st)
 {
     size_t bytes = 0;
-    HIP_TRY(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, n, rocprim::plus<int>(), st));
+    HIP_TRY(smvp::prim::exclusive_scan(nullptr, bytes, in, out, 0, n, st));
     char *tmp;
     HIP_TRY(sc.get(&tmp, bytes));
-    HIP_TRY(rocprim::exclusive_scan(tmp, bytes, in, out, 0, n, rocprim::plus<int>(), st));
+    HIP_TRY(smvp::prim::exclusive_scan(tmp, bytes, in, out, 0, n, st));
     return SMVP_OK;
 }
 
 int sort_pairs(u64 *k0, u64 *k1, unsigned *i0, unsigned *i1, int n, unsigned bits, Scratch &sc, hipStream_t st)
 {
     size_t bytes = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, k0, k1, i0, i1, (size_t)n, 0u, bits, st));
+    HIP_TRY(smvp::prim::radix_sort_pairs(nullptr, bytes, k0, k1, i0, i1, (size_t)n, 0u, bits, st));
     char *tmp;
     HIP_TRY(sc.get(&tmp, bytes));
-    HIP_TRY(rocprim::radix_sort_pairs(tmp, bytes, k0, k1, i0, i1, (size_t)n, 0u, bits, st));
+    HIP_TRY(smvp::prim::radix_sort_pairs(tmp, bytes, k0, k1, i0, i1, (size_t)n, 0u, bits, st));
     return SMVP_OK;
 }
 

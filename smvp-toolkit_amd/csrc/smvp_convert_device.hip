@@ -11,12 +11,11 @@
 // with the entry's input position as the value, so ties keep input order exactly
 // like the host's stable counting sorts.
 #include "smvp_common.h"
+#include "smvp_prim.h"
 
 #include <hip/hip_runtime.h>
 
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <vector>
@@ -183,19 +182,19 @@ int sort_entries(Scratch &sc, const smvp_coo_t *d_coo, int rows, int cols, int n
                            row_major, k0, i0, count, bad);
         HIP_TRY(hipGetLastError());
         size_t tmp_bytes = 0;
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, i0, i1, (size_t)nnz, 0u,
+        HIP_TRY(smvp::prim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, i0, i1, (size_t)nnz, 0u,
                                           (unsigned)(minor_bits + major_bits), st));
         char *tmp;
         HIP_TRY(sc.get(&tmp, tmp_bytes));
-        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, i0, i1, (size_t)nnz, 0u,
+        HIP_TRY(smvp::prim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, i0, i1, (size_t)nnz, 0u,
                                           (unsigned)(minor_bits + major_bits), st));
     }
     {
         size_t tmp_bytes = 0;
-        HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, count, start, 0, (size_t)n_major + 1, rocprim::plus<int>(), st));
+        HIP_TRY(smvp::prim::exclusive_scan(nullptr, tmp_bytes, count, start, 0, (size_t)n_major + 1, st));
         char *tmp;
         HIP_TRY(sc.get(&tmp, tmp_bytes));
-        HIP_TRY(rocprim::exclusive_scan(tmp, tmp_bytes, count, start, 0, (size_t)n_major + 1, rocprim::plus<int>(), st));
+        HIP_TRY(smvp::prim::exclusive_scan(tmp, tmp_bytes, count, start, 0, (size_t)n_major + 1, st));
     }
     int h_bad = 0;
     HIP_TRY(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -253,18 +252,18 @@ int build_row_inverse(const int *d_row_ind, int nnz, int rows, int *d_inv_ptr, i
         hipLaunchKernelGGL(row_keys, dim3(blocks_for(nnz)), dim3(256), 0, st, d_row_ind, nnz, k0, p0, count);
         HIP_TRY(hipGetLastError());
         size_t tmp_bytes = 0;
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, p0, (unsigned *)d_inv_pos, (size_t)nnz, 0u,
+        HIP_TRY(smvp::prim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, p0, (unsigned *)d_inv_pos, (size_t)nnz, 0u,
                                           (unsigned)bits_for(std::max(rows, 2)), st));
         char *tmp;
         HIP_TRY(sc.get(&tmp, tmp_bytes));
-        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, p0, (unsigned *)d_inv_pos, (size_t)nnz, 0u,
+        HIP_TRY(smvp::prim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, p0, (unsigned *)d_inv_pos, (size_t)nnz, 0u,
                                           (unsigned)bits_for(std::max(rows, 2)), st));
     }
     size_t tmp_bytes = 0;
-    HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, count, d_inv_ptr, 0, (size_t)rows + 1, rocprim::plus<int>(), st));
+    HIP_TRY(smvp::prim::exclusive_scan(nullptr, tmp_bytes, count, d_inv_ptr, 0, (size_t)rows + 1, st));
     char *tmp;
     HIP_TRY(sc.get(&tmp, tmp_bytes));
-    HIP_TRY(rocprim::exclusive_scan(tmp, tmp_bytes, count, d_inv_ptr, 0, (size_t)rows + 1, rocprim::plus<int>(), st));
+    HIP_TRY(smvp::prim::exclusive_scan(tmp, tmp_bytes, count, d_inv_ptr, 0, (size_t)rows + 1, st));
     HIP_TRY(hipStreamSynchronize(st));
     return SMVP_OK;
 }
@@ -544,16 +543,16 @@ int sort_tile_windows(const int *d_pos, int nnz, int tile, const int *d_start_po
     HIP_TRY(hipGetLastError());
     const unsigned bits = 33u + (unsigned)bits_for(ntiles + 1);
     size_t tmp_bytes = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, s0, s1, (size_t)nnz, 0u, bits, st));
+    HIP_TRY(smvp::prim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, s0, s1, (size_t)nnz, 0u, bits, st));
     char *tmp;
     HIP_TRY(sc.get(&tmp, tmp_bytes));
-    HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, s0, s1, (size_t)nnz, 0u, bits, st));
+    HIP_TRY(smvp::prim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, s0, s1, (size_t)nnz, 0u, bits, st));
     {
         size_t scan_bytes = 0;
-        HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, count, d_cache_ptr, 0, (size_t)ntiles + 1, rocprim::plus<int>(), st));
+        HIP_TRY(smvp::prim::exclusive_scan(nullptr, scan_bytes, count, d_cache_ptr, 0, (size_t)ntiles + 1, st));
         char *scan_tmp;
         HIP_TRY(sc.get(&scan_tmp, scan_bytes));
-        HIP_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, count, d_cache_ptr, 0, (size_t)ntiles + 1, rocprim::plus<int>(), st));
+        HIP_TRY(smvp::prim::exclusive_scan(scan_tmp, scan_bytes, count, d_cache_ptr, 0, (size_t)ntiles + 1, st));
     }
     int total = 0;
     HIP_TRY(hipMemcpyAsync(&total, d_cache_ptr + ntiles, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -617,20 +616,20 @@ int build_tile_half_streams(const int *d_pos, int nnz, int tile, const int *d_st
         HIP_TRY(hipGetLastError());
         const unsigned bits = 33u + (unsigned)bits_for(ntiles + 1);
         size_t tmp_bytes = 0;
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, s0, s1, (size_t)nnz, 0u, bits, st));
+        HIP_TRY(smvp::prim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, s0, s1, (size_t)nnz, 0u, bits, st));
         char *tmp;
         HIP_TRY(sc.get(&tmp, tmp_bytes));
-        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, s0, s1, (size_t)nnz, 0u, bits, st));
+        HIP_TRY(smvp::prim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, s0, s1, (size_t)nnz, 0u, bits, st));
         hipLaunchKernelGGL(diagonal_run_heads, dim3(blocks_for(nnz)), dim3(256), 0, st, k1, nnz, tile, d_start_pos, num_diag, dg, head, rcount);
         HIP_TRY(hipGetLastError());
         size_t scan_bytes = 0, scan2 = 0;
-        HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, count, d_cache_ptr, 0, (size_t)ntiles + 1, rocprim::plus<int>(), st));
-        HIP_TRY(rocprim::inclusive_scan(nullptr, scan2, head, rid, (size_t)nnz, rocprim::plus<int>(), st));
+        HIP_TRY(smvp::prim::exclusive_scan(nullptr, scan_bytes, count, d_cache_ptr, 0, (size_t)ntiles + 1, st));
+        HIP_TRY(smvp::prim::inclusive_scan(nullptr, scan2, head, rid, (size_t)nnz, st));
         char *scan_tmp;
         HIP_TRY(sc.get(&scan_tmp, std::max(scan_bytes, scan2)));
-        HIP_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, count, d_cache_ptr, 0, (size_t)ntiles + 1, rocprim::plus<int>(), st));
-        HIP_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, rcount, d_run_ptr, 0, (size_t)ntiles + 1, rocprim::plus<int>(), st));
-        HIP_TRY(rocprim::inclusive_scan(scan_tmp, scan2, head, rid, (size_t)nnz, rocprim::plus<int>(), st));
+        HIP_TRY(smvp::prim::exclusive_scan(scan_tmp, scan_bytes, count, d_cache_ptr, 0, (size_t)ntiles + 1, st));
+        HIP_TRY(smvp::prim::exclusive_scan(scan_tmp, scan_bytes, rcount, d_run_ptr, 0, (size_t)ntiles + 1, st));
+        HIP_TRY(smvp::prim::inclusive_scan(scan_tmp, scan2, head, rid, (size_t)nnz, st));
         HIP_TRY(hipMemcpyAsync(&total, d_cache_ptr + ntiles, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(&nruns, d_run_ptr + ntiles, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -747,10 +746,10 @@ extern "C" int smvp_tjds_from_coo_device(const smvp_coo_t *d_coo, int rows, int 
         hipLaunchKernelGGL(length_keys, dim3(blocks_for(cols)), dim3(256), 0, st, col_len, cols, lk0, lc0);
         HIP_TRY(hipGetLastError());
         size_t tmp_bytes = 0;
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, lk0, lk1, lc0, lc1, (size_t)cols, 0u, 32u, st));
+        HIP_TRY(smvp::prim::radix_sort_pairs(nullptr, tmp_bytes, lk0, lk1, lc0, lc1, (size_t)cols, 0u, 32u, st));
         char *tmp;
         HIP_TRY(sc.get(&tmp, tmp_bytes));
-        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, lk0, lk1, lc0, lc1, (size_t)cols, 0u, 32u, st));
+        HIP_TRY(smvp::prim::radix_sort_pairs(tmp, tmp_bytes, lk0, lk1, lc0, lc1, (size_t)cols, 0u, 32u, st));
         hipLaunchKernelGGL(invert_perm, dim3(blocks_for(cols)), dim3(256), 0, st, lc1, cols, d_perm, where);
         HIP_TRY(hipGetLastError());
         unsigned first_key = 0;
@@ -769,10 +768,10 @@ extern "C" int smvp_tjds_from_coo_device(const smvp_coo_t *d_coo, int rows, int 
     HIP_TRY(hipGetLastError());
     {
         size_t tmp_bytes = 0;
-        HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, width, d_start_pos, 0, (size_t)longest + 1, rocprim::plus<int>(), st));
+        HIP_TRY(smvp::prim::exclusive_scan(nullptr, tmp_bytes, width, d_start_pos, 0, (size_t)longest + 1, st));
         char *tmp;
         HIP_TRY(sc.get(&tmp, tmp_bytes));
-        HIP_TRY(rocprim::exclusive_scan(tmp, tmp_bytes, width, d_start_pos, 0, (size_t)longest + 1, rocprim::plus<int>(), st));
+        HIP_TRY(smvp::prim::exclusive_scan(tmp, tmp_bytes, width, d_start_pos, 0, (size_t)longest + 1, st));
     }
     if (nnz > 0) {
         hipLaunchKernelGGL(scatter_tjds, dim3(blocks_for(nnz)), dim3(256), 0, st, d_coo, order, nnz, col_start, where,
@@ -924,10 +923,10 @@ int build_colsweep_plan(const int *d_row_ptr, const int *d_col_ind, const double
         HIP_TRY(hipGetLastError());
         const unsigned bits = 32u + (unsigned)bits_for(nstrips + 1);
         size_t tmp_bytes = 0;
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, i0, i1, (size_t)nnz, 0u, bits, st));
+        HIP_TRY(smvp::prim::radix_sort_pairs(nullptr, tmp_bytes, k0, k1, i0, i1, (size_t)nnz, 0u, bits, st));
         char *tmp;
         HIP_TRY(sc.get(&tmp, tmp_bytes));
-        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, i0, i1, (size_t)nnz, 0u, bits, st));
+        HIP_TRY(smvp::prim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, i0, i1, (size_t)nnz, 0u, bits, st));
         hipLaunchKernelGGL(sweep_gather, dim3(blocks_for(nnz)), dim3(256), 0, st, k1, i1, d_val, lr, nnz, d_e_col, d_e_val, lr_sorted);
         HIP_TRY(hipGetLastError());
         if (parts > 1) {

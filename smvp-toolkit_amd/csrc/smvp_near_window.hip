@@ -28,10 +28,9 @@
 //
 // The plan is built on the device (rocPRIM sort and scans: set-up work).
 #include "smvp_common.h"
+#include "smvp_prim.h"
 #include "smvp_kernels.h"
 
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <atomic>
@@ -384,10 +383,10 @@ __global__ __launch_bounds__(256) void nw_emit_outside(const int *__restrict__ o
 int scan_exclusive(const int *in, int *out, size_t n, Scratch &sc, hipStream_t st)
 {
     size_t bytes = 0;
-    HIP_TRY(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, n, rocprim::plus<int>(), st));
+    HIP_TRY(smvp::prim::exclusive_scan(nullptr, bytes, in, out, 0, n, st));
     char *tmp;
     HIP_TRY(sc.get(&tmp, bytes));
-    HIP_TRY(rocprim::exclusive_scan(tmp, bytes, in, out, 0, n, rocprim::plus<int>(), st));
+    HIP_TRY(smvp::prim::exclusive_scan(tmp, bytes, in, out, 0, n, st));
     return SMVP_OK;
 }
 
@@ -460,10 +459,10 @@ int build_near_window(const int *near_ptr, const int *near_col, const double *ne
         while (bits < 32 && (1ull << bits) < (unsigned long long)P.nblocks * 32ull)
             ++bits;
         size_t bytes = 0;
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, k0, k1, i0, i1, (size_t)rows, 0u, bits, st));
+        HIP_TRY(smvp::prim::radix_sort_pairs(nullptr, bytes, k0, k1, i0, i1, (size_t)rows, 0u, bits, st));
         char *tmp;
         HIP_TRY(sc.get(&tmp, bytes));
-        HIP_TRY(rocprim::radix_sort_pairs(tmp, bytes, k0, k1, i0, i1, (size_t)rows, 0u, bits, st));
+        HIP_TRY(smvp::prim::radix_sort_pairs(tmp, bytes, k0, k1, i0, i1, (size_t)rows, 0u, bits, st));
     }
     if (int rc = scan_exclusive(is_long, lscan, (size_t)rows + 1, sc, st))
         return rc;

@@ -1368,6 +1368,24 @@ def test_bench_starts_its_own_ranks(torch, tmp_path):
     assert not left, left
 
 
+def test_device_primitives(torch, tmp_path):
+    """smvp_prim.h -- the hand-written stable radix sort of (key, value) pairs and the prefix sums that the device-side converters
+    and the plan builders stand on (rocPRIM until round 5) -- against std::stable_sort and running sums on the host: 64- and 32-bit
+    keys, bit windows, few distinct keys (stability), sizes around every tile edge up to 20 M, in-place scans, three scan levels.
+    tests/prim_check.hip is compiled here with hipcc (the header is all templates)."""
+    import shutil
+
+    from conftest import ROOT
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "prim_check")
+    b = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "smvp-toolkit_amd", "csrc"),
+                        os.path.join(ROOT, "tests", "prim_check.hip"), "-o", exe], capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-2000:]
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "prim ok" in p.stdout, p.stdout[-2000:] + p.stderr[-1000:]
+
+
 # --------------------------------------------------- device-side format conversion
 def _coo_to_device(torch, coo):
     raw = np.ascontiguousarray(coo, dtype=sm.COO_DTYPE).view(np.uint8)
