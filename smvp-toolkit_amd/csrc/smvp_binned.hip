@@ -29,7 +29,7 @@
 // same from run to run, bit for bit.  A row's sum is (near part, left to right for a row of at most 16 near entries) + (far
 // part, left to right).  Pass A needs x only: with K6 it runs beside the near part on a stream of its own (engine).
 //
-// The plan -- near arrays, both streams, the bins -- is built on the device (rocPRIM sorts and scans: set-up work).
+// The plan -- near arrays, both streams, the bins -- is built on the device (the sorts and scans of smvp_prim.h: set-up work).
 #include "smvp_common.h"
 #include "smvp_prim.h"
 #include "smvp_kernels.h"

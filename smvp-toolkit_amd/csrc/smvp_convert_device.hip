@@ -6,7 +6,7 @@
 // reference's own TJDS build is O(nnz * cols) (main-cli.c:894-904), the host
 // converter here takes 15 s for 119 M entries, this path tens of milliseconds.
 //
-// The heavy lifting is two stable LSD radix sorts (rocPRIM device primitives --
+// The heavy lifting is two stable LSD radix sorts (smvp_prim.h: hand-written, 8 bits per pass --
 // setup work, not the timed product) on keys packed as major * 2^bits(minor) + minor,
 // with the entry's input position as the value, so ties keep input order exactly
 // like the host's stable counting sorts.

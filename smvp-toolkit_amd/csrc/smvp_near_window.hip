@@ -26,7 +26,7 @@
 // than kNwLongCap long rows, or a band wider than 4096, makes the plan unsuitable: the near part then stays on the tile
 // kernel.  No atomics: the same bits from run to run.
 //
-// The plan is built on the device (rocPRIM sort and scans: set-up work).
+// The plan is built on the device (the sort and scans of smvp_prim.h: set-up work).
 #include "smvp_common.h"
 #include "smvp_prim.h"
 #include "smvp_kernels.h"
