@@ -24,7 +24,10 @@ namespace smvp {
 namespace prim {
 
 constexpr int kScanBlock = 256, kScanItems = 4, kScanTile = kScanBlock * kScanItems;
-constexpr int kSortBlock = 256, kSortItems = 8, kSortTile = kSortBlock * kSortItems, kSortWaves = kSortBlock / 64;
+#ifndef SMVP_SORT_ITEMS
+#define SMVP_SORT_ITEMS 8  // elements per thread and pass (tests/prim_check.hip times other values)
+#endif
+constexpr int kSortBlock = 256, kSortItems = SMVP_SORT_ITEMS, kSortTile = kSortBlock * kSortItems, kSortWaves = kSortBlock / 64;
 constexpr int kRadixBits = 8, kRadix = 1 << kRadixBits;
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }

@@ -90,8 +90,47 @@ static void check_scan(size_t n, bool inclusive, bool in_place, int init, unsign
     CK(hipFree(d_in)); CK(hipFree(d_out)); CK(hipFree(tmp));
 }
 
-int main()
+// `prim_check time`: milliseconds of one sort of 2^27 pairs (64-bit keys, 44 bits) and of one scan of 2^27 ints
+static void timing()
 {
+    const size_t n = (size_t)1 << 27;
+    unsigned long long *k0, *k1;
+    unsigned *v0, *v1;
+    CK(hipMalloc(&k0, n * 8)); CK(hipMalloc(&k1, n * 8)); CK(hipMalloc(&v0, n * 4)); CK(hipMalloc(&v1, n * 4));
+    std::vector<unsigned long long> h(n);
+    std::mt19937_64 rng(7);
+    for (auto &x : h) x = rng() & ((1ull << 44) - 1);
+    CK(hipMemcpy(k0, h.data(), n * 8, hipMemcpyHostToDevice));
+    CK(hipMemset(v0, 0, n * 4));
+    size_t bytes = 0;
+    CK(smvp::prim::radix_sort_pairs((void *)nullptr, bytes, (const unsigned long long *)k0, k1, (const unsigned *)v0, v1, n, 0u, 44u, nullptr));
+    void *tmp;
+    CK(hipMalloc(&tmp, bytes));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(a));
+        CK(smvp::prim::radix_sort_pairs(tmp, bytes, (const unsigned long long *)k0, k1, (const unsigned *)v0, v1, n, 0u, 44u, nullptr));
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        printf("sort 2^27 pairs, 44 bits, %d items per thread: %.2f ms\n", smvp::prim::kSortItems, ms);
+    }
+    size_t sb = 0;
+    CK(smvp::prim::exclusive_scan(nullptr, sb, (const int *)v0, (int *)v1, 0, n, nullptr));
+    void *st; CK(hipMalloc(&st, sb));
+    CK(hipEventRecord(a));
+    CK(smvp::prim::exclusive_scan(st, sb, (const int *)v0, (int *)v1, 0, n, nullptr));
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    printf("exclusive scan of 2^27 ints: %.2f ms\n", ms);
+}
+
+int main(int argc, char **)
+{
+    if (argc > 1) {
+        timing();
+        return 0;
+    }
     const size_t sizes[] = {0, 1, 2, 63, 64, 65, 255, 256, 257, 511, 512, 513, 2047, 2048, 2049, 4095, 4097, 100000, 1048576 + 3, 5000000 + 17};
     unsigned seed = 1;
     for (size_t n : sizes) {
