@@ -196,7 +196,10 @@ enum {
                                          into partial sums of its own -- strips 2x / 4x as tall for the same rows per workgroup,
                                          which is what a block of few rows (one rank's share of a sharded matrix) lacks; a row's
                                          sum is then its partial sums added part by part: the same from run to run, inside the
-                                         rounding bound, NOT bit-identical to the serial loop.  Never picked by AUTO */
+                                         rounding bound, NOT bit-identical to the serial loop.  parts = 8: one column part per XCD
+                                         (workgroup b of a launch runs on XCD b % 8 and sweeps eighth b % 8 of the columns for
+                                         the four whole strips of row group b / 8; the eight partial sums of a row meet in 8 *
+                                         rows doubles of scratch and are added by a second kernel).  Never picked by AUTO */
     SMVP_CSR_KERNEL_BINNED = 5        /* for matrices with a band around the diagonal plus many entries far from it
                                          (anywhere in an operand much larger than the L2): the entries are kept a second
                                          time, split by |column - row| > band.  The near part is summed out of a row
@@ -385,7 +388,7 @@ int smvp_sharded_info(const smvp_sharded_t *h, int *ngpus, int *rows_per_gpu); /
 int smvp_sharded_layout(const smvp_sharded_t *h, int *chunks, int *bounds, int *chunk_bounds);
 void smvp_sharded_destroy(smvp_sharded_t *h);
 
-#define SMVP_CSR_SWEEP_PARTS(rows_per_block, parts) ((rows_per_block) | (((parts) == 4 ? 2 : (parts) == 2 ? 1 : 0) << 24))
+#define SMVP_CSR_SWEEP_PARTS(rows_per_block, parts) ((rows_per_block) | (((parts) == 8 ? 3 : (parts) == 4 ? 2 : (parts) == 2 ? 1 : 0) << 24))
 /* for experiments: the same with the 256-entry chunks a wavefront keeps in flight forced to 1, 2 or 4 (0 = the library's rule) */
 #define SMVP_CSR_SWEEP_PARAM(rows_per_block, parts, chunks) \
     (SMVP_CSR_SWEEP_PARTS(rows_per_block, parts) | (((chunks) == 4 ? 3 : (chunks) == 2 ? 2 : (chunks) == 1 ? 1 : 0) << 26))

@@ -901,7 +901,7 @@ int build_colsweep_plan(const int *d_row_ptr, const int *d_col_ind, const double
                         unsigned short *d_e_row, hipStream_t st)
 {
     if (strip_rows < 1 || strip_rows > (1 << row_bits) || row_bits < 1 || row_bits > 15 || chunk < 64 ||
-        turn_cap != (1 << (16 - row_bits)) - 1 || (parts != 1 && parts != 2 && parts != 4))
+        turn_cap != (1 << (16 - row_bits)) - 1 || (parts != 1 && parts != 2 && parts != 4 && parts != 8))
         return smvp::fail(SMVP_ERR_INVALID, "build_colsweep_plan: bad strip shape");
     const unsigned part_width = (unsigned)std::max(1, (int)(((long long)std::max(cols, 1) + parts - 1) / parts));
     const int nstrips = (rows + strip_rows - 1) / strip_rows;

@@ -158,6 +158,7 @@ struct smvp_csr {
     // COLSWEEP: the entries a second time, every strip of sweep_rb / 4 rows sorted by column (built on the device);
     // sweep_rb = rows per workgroup (four wavefronts, one strip each)
     int sweep_rb = 0, sweep_per_launch = 0;
+    double *d_sweep_part = nullptr;  // COLSWEEP with XCD-private column parts: 8 * rows partial sums
     int sweep_parts = 1;       // COLSWEEP: column parts per strip (1: every row summed in the serial loop's order; 2 / 4: see sweep_param)
     double spread = -2.0;  // share of gathers that pull their own line of x (csr_gather_spread); -2: not measured yet
     long long *d_sweep_ptr = nullptr;
@@ -198,9 +199,10 @@ void free_binned(smvp_csr *h)
 
 void free_sweep_plan(smvp_csr *h)
 {
-    for (void *p : {(void *)h->d_sweep_ptr, (void *)h->d_sweep_col, (void *)h->d_sweep_val, (void *)h->d_sweep_row})
+    for (void *p : {(void *)h->d_sweep_ptr, (void *)h->d_sweep_col, (void *)h->d_sweep_val, (void *)h->d_sweep_row, (void *)h->d_sweep_part})
         if (p)
             (void)hipFree(p);
+    h->d_sweep_part = nullptr;
     h->d_sweep_ptr = nullptr;
     h->d_sweep_col = nullptr;
     h->d_sweep_val = nullptr;
@@ -298,15 +300,17 @@ void choose_sweep_shape(int rows, int cols, int nnz, int want_rb, int *rb, int *
 // two / four (what the environment switch SMVP_SWEEP_G used to say; tools/exp_colsweep.py --g).
 constexpr int kSweepPartsShift = 24, kSweepChunksShift = 26;
 inline int sweep_param_rb(int param) { return param & ((1 << kSweepPartsShift) - 1); }
-inline int sweep_param_parts(int param) { return 1 << ((param >> kSweepPartsShift) & 3); }
+inline int sweep_param_parts(int param) { return 1 << ((param >> kSweepPartsShift) & 3); }  // (8 = one part per XCD, below)
 inline int sweep_param_chunks(int param) { const int c = (param >> kSweepChunksShift) & 3; return c == 3 ? 4 : c; }
 bool sweep_param_ok(int param)
 {
     const int rb = sweep_param_rb(param), parts = sweep_param_parts(param);
-    if (param < 0 || (param >> (kSweepChunksShift + 2)) != 0 || ((param >> kSweepPartsShift) & 3) > 2)
+    if (param < 0 || (param >> (kSweepChunksShift + 2)) != 0)
         return false;
     if (rb == 0)
         return true;  // (height chosen; the parts are honoured where the chosen height leaves room for them)
+    if (parts == smvp::kSweepXcdParts)  // XCD-private parts: the workgroup's four strips are whole strips of rb / 4 rows
+        return rb >= 256 && rb % 4 == 0 && rb <= kSweepMaxRb;
     return rb >= 256 && rb % 4 == 0 && (long long)rb * parts <= kSweepMaxRb;
 }
 
@@ -315,10 +319,24 @@ int build_sweep_plan(smvp_csr *h, int want)
     free_sweep_plan(h);
     const int want_rb = sweep_param_rb(want);
     h->sweep_parts = sweep_param_parts(want);
-    choose_sweep_shape(h->rows, h->cols, h->nnz, want_rb, &h->sweep_rb, &h->sweep_per_launch);
-    while (h->sweep_parts > 1 && (long long)h->sweep_rb * h->sweep_parts > kSweepMaxRb)
-        h->sweep_parts >>= 1;  // (a chosen height may leave room for fewer parts than asked)
-    const int strip_rows = h->sweep_rb * h->sweep_parts / smvp::kSweepWaves;
+    const bool xcd = h->sweep_parts == smvp::kSweepXcdParts;
+    if (xcd) {
+        // XCD-private column parts (SMVP_CSR_SWEEP_PARTS(rb, 8)): a generation of 256 workgroups = 32 row groups x 8 parts; the height is the
+        // caller's, or the one that cuts the rows into whole generations with the tallest strips the LDS takes
+        int rb = want_rb;
+        if (rb == 0) {
+            const long long per_gen_max = 32ll * kSweepMaxRb;
+            const long long gens = std::max<long long>(1, ((long long)h->rows + per_gen_max - 1) / per_gen_max);
+            rb = (int)std::min<long long>(kSweepMaxRb, std::max<long long>(256, (((long long)h->rows + 32 * gens - 1) / (32 * gens) + 3) / 4 * 4));
+        }
+        h->sweep_rb = rb;
+        h->sweep_per_launch = 256;
+    } else {
+        choose_sweep_shape(h->rows, h->cols, h->nnz, want_rb, &h->sweep_rb, &h->sweep_per_launch);
+        while (h->sweep_parts > 1 && (long long)h->sweep_rb * h->sweep_parts > kSweepMaxRb)
+            h->sweep_parts >>= 1;  // (a chosen height may leave room for fewer parts than asked)
+    }
+    const int strip_rows = xcd ? h->sweep_rb / smvp::kSweepWaves : h->sweep_rb * h->sweep_parts / smvp::kSweepWaves;
     h->sweep_g = smvp::sweep_chunks_in_flight(strip_rows, sweep_param_chunks(want));
     if (const hipError_t pe = smvp::prepare_csr_colsweep(); pe != hipSuccess)
         return smvp::fail(SMVP_ERR_HIP, "the column sweep cannot have its LDS: %s", hipGetErrorString(pe));
@@ -327,7 +345,8 @@ int build_sweep_plan(smvp_csr *h, int want)
     if (hipMalloc((void **)&h->d_sweep_ptr, ((size_t)nstrips * h->sweep_parts + 2) * sizeof(long long)) != hipSuccess ||
         hipMalloc((void **)&h->d_sweep_col, n * sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&h->d_sweep_val, n * sizeof(double)) != hipSuccess ||
-        hipMalloc((void **)&h->d_sweep_row, n * sizeof(unsigned short)) != hipSuccess)
+        hipMalloc((void **)&h->d_sweep_row, n * sizeof(unsigned short)) != hipSuccess ||
+        (xcd && hipMalloc((void **)&h->d_sweep_part, sizeof(double) * smvp::kSweepXcdParts * (size_t)std::max(h->rows, 1)) != hipSuccess))
         return smvp::fail(SMVP_ERR_ALLOC, "cannot allocate the column-sweep plan (%d entries)", h->nnz);
     return smvp::build_colsweep_plan(h->d_row_ptr, h->d_col_ind, h->d_val, h->rows, h->cols, h->nnz, strip_rows, h->sweep_parts, smvp::kSweepChunk,
                                      smvp::kSweepRowBits, smvp::kSweepTurnCap, h->d_sweep_ptr, h->d_sweep_col, h->d_sweep_val, h->d_sweep_row, nullptr);
@@ -856,7 +875,7 @@ extern "C" int smvp_csr_get_kernel(const smvp_csr_t *h, int *kernel, int *param)
         *kernel = h->kernel;
     if (param)
         *param = h->kernel == SMVP_CSR_KERNEL_VECTOR ? h->lanes_per_row
-                 : h->kernel == SMVP_CSR_KERNEL_COLSWEEP ? (h->sweep_rb | ((h->sweep_parts == 4 ? 2 : h->sweep_parts == 2 ? 1 : 0) << kSweepPartsShift))
+                 : h->kernel == SMVP_CSR_KERNEL_COLSWEEP ? (h->sweep_rb | ((h->sweep_parts == 8 ? 3 : h->sweep_parts == 4 ? 2 : h->sweep_parts == 2 ? 1 : 0) << kSweepPartsShift))
                  : h->kernel == SMVP_CSR_KERNEL_BINNED   ? h->bin.band
                                                          : h->vpt * smvp::kStreamBlock;
     return SMVP_OK;
@@ -978,7 +997,8 @@ static int csr_spmv_impl(smvp_csr_t *h, const double *d_x, double *d_y, void *st
         e = smvp::launch_binned_sums(h->bin, d_y, st);
     } else if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP)
         e = smvp::launch_csr_colsweep(h->d_sweep_ptr, h->d_sweep_col, h->d_sweep_val, h->d_sweep_row, d_x, d_y, h->rows,
-                                      h->sweep_rb * h->sweep_parts / smvp::kSweepWaves, h->sweep_parts, h->sweep_per_launch, h->sweep_g, st);
+                                      (h->sweep_parts == smvp::kSweepXcdParts ? h->sweep_rb : h->sweep_rb * h->sweep_parts) / smvp::kSweepWaves,
+                                      h->sweep_parts, h->sweep_per_launch, h->sweep_g, h->d_sweep_part, st);
     else if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
         e = smvp::launch_csr_vector(h->lanes_per_row, h->d_row_ptr, h->d_col_ind, h->d_val, d_x, d_y, h->rows, st);
     else if (h->kernel == SMVP_CSR_KERNEL_STREAM) {
@@ -1014,7 +1034,9 @@ extern "C" int smvp_csr_describe(const smvp_csr_t *h, char *kernel_name, size_t 
                      h->near ? h->near->vpt : 0, h->near ? (h->near->d_col16 ? smvp::kFlavorCsr16 : h->near->flavor) : 0,
                      h->bin.slots, h->bin.threads_b);
         else if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP)
-            if (h->sweep_parts > 1)
+            if (h->sweep_parts == smvp::kSweepXcdParts)
+                snprintf(kernel_name, cap, "csr_colsweep<%d> (8 column parts, one per XCD) + sweep_combine", h->sweep_g);
+            else if (h->sweep_parts > 1)
                 snprintf(kernel_name, cap, "csr_colsweep<%d> (%d column parts)", h->sweep_g, h->sweep_parts);
             else
                 snprintf(kernel_name, cap, "csr_colsweep<%d>", h->sweep_g);
@@ -1037,8 +1059,9 @@ extern "C" int smvp_csr_plan_launches(const smvp_csr_t *h, int *launches)
         return smvp::fail(SMVP_ERR_INVALID, "smvp_csr_plan_launches: bad argument");
     *launches = 1;
     if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP && h->sweep_rb > 0 && h->sweep_per_launch > 0) {
-        const int nwg = (h->rows + h->sweep_rb - 1) / h->sweep_rb;
-        *launches = std::max(1, (nwg + h->sweep_per_launch - 1) / h->sweep_per_launch);
+        const bool xcd = h->sweep_parts == smvp::kSweepXcdParts;
+        const int nwg = (h->rows + h->sweep_rb - 1) / h->sweep_rb * (xcd ? smvp::kSweepXcdParts : 1);
+        *launches = std::max(1, (nwg + h->sweep_per_launch - 1) / h->sweep_per_launch) + (xcd ? 1 : 0);  // (+ sweep_combine)
     } else if (h->kernel == SMVP_CSR_KERNEL_STREAM_CARRY && h->ntiles > 1) {
         *launches = 2;
     } else if (h->kernel == SMVP_CSR_KERNEL_BINNED && h->bin.nw.on) {
@@ -1058,8 +1081,9 @@ static double csr_plan_bytes(const smvp_csr_t *h)
     if (h->kernel == SMVP_CSR_KERNEL_BINNED)
         return (double)h->bin.plan_bytes + (h->near ? csr_plan_bytes(h->near) : 0.0);
     if (h->kernel == SMVP_CSR_KERNEL_COLSWEEP) {
-        const int strip_rows = std::max(1, h->sweep_rb * h->sweep_parts / smvp::kSweepWaves);
-        return 14.0 * n + 8.0 * ((double)((h->rows + strip_rows - 1) / strip_rows) * h->sweep_parts + 2);
+        const bool xcd = h->sweep_parts == smvp::kSweepXcdParts;
+        const int strip_rows = std::max(1, (xcd ? h->sweep_rb : h->sweep_rb * h->sweep_parts) / smvp::kSweepWaves);
+        return 14.0 * n + 8.0 * ((double)((h->rows + strip_rows - 1) / strip_rows) * h->sweep_parts + 2) + (xcd ? 64.0 * h->rows : 0.0);
     }
     if (h->kernel == SMVP_CSR_KERNEL_VECTOR)
         return 0.0;

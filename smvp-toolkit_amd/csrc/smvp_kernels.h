@@ -14,6 +14,7 @@ constexpr int kSweepBlock = 256;   // threads per block, csr_colsweep: four wave
 constexpr int kSweepWaves = kSweepBlock / 64;
 constexpr int kSweepUnroll = 4;    // stream entries per lane and pass: a wavefront takes its strip 256 entries at a time
 constexpr int kSweepChunk = 64 * kSweepUnroll;
+constexpr int kSweepXcdParts = 8;  // XCD-private column parts: one per XCD (workgroup b of a launch runs on XCD b % 8)
 constexpr int kSweepRowBits = 13;  // a strip holds at most 8192 rows (64 KB of sums in LDS; four strips of 5120 fill a CU's 160 KB) ...
 constexpr int kSweepTurnCap = (1 << (16 - kSweepRowBits)) - 1;  // ... and the 16-bit row word carries the entry's turn, capped
 constexpr int kTjdsBlock = 256;     // permuted columns per work item
@@ -89,7 +90,8 @@ hipError_t launch_normalize_max(double *v, long long n, unsigned long long *scra
 hipError_t launch_fill(double *p, double v, long long n, hipStream_t stream);
 
 hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, const double *e_val, const unsigned short *e_row,
-                               const double *x, double *y, int rows, int strip_rows, int parts, int per_launch, int g, hipStream_t stream);
+                               const double *x, double *y, int rows, int strip_rows, int parts, int per_launch, int g, double *ypart,
+                               hipStream_t stream);  // parts == kSweepXcdParts: ypart = 8 * rows doubles of scratch
 hipError_t prepare_csr_colsweep();  // once per plan build, on the plan's device: the kernel may use up to 160 KB of dynamic LDS
 int sweep_chunks_in_flight(int strip_rows, int asked);  // the G of csr_colsweep<G> a strip height runs with (asked = 1 | 2 | 4 overrides; plan time only)
 // entries of 64 K-entry samples of a CSR matrix that gather from distinct 128-byte lines of x (see csr_line_spread)

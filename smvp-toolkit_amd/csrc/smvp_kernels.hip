@@ -1448,7 +1448,7 @@ template <int G>
 __global__ __launch_bounds__(kSweepBlock) void csr_colsweep(
     const long long *__restrict__ strip_ptr, const int *__restrict__ e_col, const double *__restrict__ e_val,
     const unsigned short *__restrict__ e_row, const double *__restrict__ x, double *__restrict__ y, int rows, int strip_rows,
-    int nstrips, int wg_first, int parts)
+    int nstrips, int wg_first, int parts, double *__restrict__ ypart, long long ypart_stride)
 {
     constexpr int U = kSweepUnroll, E = G * U;
     constexpr long long STEP = (long long)G * kSweepChunk;
@@ -1456,8 +1456,20 @@ __global__ __launch_bounds__(kSweepBlock) void csr_colsweep(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     // `strip` numbers the STREAMS: strip * 1 (parts == 1: a stream is a strip's) or real strip * parts + column part
-    const int strip = (wg_first + (int)blockIdx.x) * kSweepWaves + wave;
-    const bool live = strip < nstrips * parts;
+    int strip = (wg_first + (int)blockIdx.x) * kSweepWaves + wave;
+    bool live = strip < nstrips * parts;
+    long long part_rows0 = -1;  // parts == kSweepXcdParts: where this wavefront's partial sums go in ypart
+    if (parts == kSweepXcdParts) {
+        // XCD-private column parts: workgroup b of a launch runs on XCD b % 8 and takes column part b % 8 of the four strips of row
+        // group b / 8 -- every XCD gathers from its own eighth of x only; the wavefronts keep whole strips, the eight partial sums
+        // of a row meet in ypart and are added part by part by sweep_combine (reproducible, not the serial loop's bits)
+        const int b = wg_first + (int)blockIdx.x, part = b % kSweepXcdParts, real = (b / kSweepXcdParts) * kSweepWaves + wave;
+        live = real < nstrips;
+        strip = real * kSweepXcdParts + part;
+        part_rows0 = (long long)part * ypart_stride + (long long)real * strip_rows;
+        if (!live)
+            return;
+    }
     if (!live && parts == 1)
         return;  // (no barrier in the one-part form)
     // volatile: every access is issued where it stands -- another lane's earlier store must be seen; the LDS address
@@ -1547,6 +1559,12 @@ __global__ __launch_bounds__(kSweepBlock) void csr_colsweep(
             w[e] = wn[e];
         }
     }
+    if (parts == kSweepXcdParts) {
+        const long long r0 = part_rows0 - (part_rows0 / ypart_stride) * ypart_stride;  // the strip's first row
+        for (int i = lane; i < strip_rows && r0 + i < rows; i += 64)
+            ypart[part_rows0 + i] = sums[i];  // (read again by sweep_combine: through the caches)
+        return;
+    }
     if (parts == 1) {
         const long long r0 = (long long)strip * strip_rows;
         for (int i = lane; i < strip_rows && r0 + i < rows; i += 64)
@@ -1569,6 +1587,19 @@ __global__ __launch_bounds__(kSweepBlock) void csr_colsweep(
             __builtin_nontemporal_store(acc, &y[r0 + i]);
         }
     }
+}
+
+// XCD-private column parts: y[r] = the eight partial sums of row r, added in the order of the parts
+__global__ __launch_bounds__(256) void sweep_combine(const double *__restrict__ ypart, long long stride, double *__restrict__ y, int rows)
+{
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows)
+        return;
+    double acc = ypart[r];
+#pragma unroll
+    for (int q = 1; q < kSweepXcdParts; ++q)
+        acc += ypart[(long long)q * stride + r];
+    __builtin_nontemporal_store(acc, &y[r]);
 }
 
 // Chunks in flight per wavefront.  A launch generation is one workgroup per CU (four wavefronts): with tall strips two chunks
@@ -1598,14 +1629,18 @@ hipError_t prepare_csr_colsweep()
 }
 
 hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, const double *e_val, const unsigned short *e_row,
-                               const double *x, double *y, int rows, int strip_rows, int parts, int per_launch, int g, hipStream_t stream)
+                               const double *x, double *y, int rows, int strip_rows, int parts, int per_launch, int g, double *ypart,
+                               hipStream_t stream)
 {
     if (rows <= 0)
         return hipSuccess;
-    if (parts != 1 && parts != 2 && parts != 4)
+    const bool xcd = parts == kSweepXcdParts;
+    if ((parts != 1 && parts != 2 && parts != 4 && !xcd) || (xcd && (!ypart || (per_launch > 0 && per_launch % kSweepXcdParts != 0))))
         return hipErrorInvalidValue;
     const int nstrips = (rows + strip_rows - 1) / strip_rows;
-    const int nwg = (int)(((long long)nstrips * parts + kSweepWaves - 1) / kSweepWaves);
+    const int nwg = xcd ? (nstrips + kSweepWaves - 1) / kSweepWaves * kSweepXcdParts
+                        : (int)(((long long)nstrips * parts + kSweepWaves - 1) / kSweepWaves);
+    const long long ypart_stride = rows;
     const size_t lds = sizeof(double) * (size_t)strip_rows * kSweepWaves;
     if (per_launch <= 0)
         per_launch = nwg;
@@ -1615,7 +1650,7 @@ hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, con
         const unsigned grid = (unsigned)(nwg - first < per_launch ? nwg - first : per_launch);
 #define SMVP_SWEEP(GG)                                                                                                   \
     hipLaunchKernelGGL(csr_colsweep<GG>, dim3(grid), dim3(kSweepBlock), lds, stream, strip_ptr, e_col, e_val, e_row, x, y, \
-                       rows, strip_rows, nstrips, first, parts)
+                       rows, strip_rows, nstrips, first, parts, ypart, ypart_stride)
         if (g == 4)
             SMVP_SWEEP(4);
         else if (g == 2)
@@ -1624,6 +1659,8 @@ hipError_t launch_csr_colsweep(const long long *strip_ptr, const int *e_col, con
             SMVP_SWEEP(1);
 #undef SMVP_SWEEP
     }
+    if (xcd)
+        hipLaunchKernelGGL(sweep_combine, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, ypart, ypart_stride, y, rows);
     return hipGetLastError();
 }
 

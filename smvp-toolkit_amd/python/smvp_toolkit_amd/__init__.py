@@ -59,7 +59,7 @@ class option:
 def sweep_parts(rows_per_block, parts, chunks=0):
     """SMVP_CSR_SWEEP_PARTS / SMVP_CSR_SWEEP_PARAM: the column sweep's kernel parameter with 2 or 4 column parts per strip and,
     for experiments, the chunks a wavefront keeps in flight forced to 1, 2 or 4 (include/smvp_amd.h)."""
-    return int(rows_per_block) | ({1: 0, 2: 1, 4: 2}[int(parts)] << 24) | ({0: 0, 1: 1, 2: 2, 4: 3}[int(chunks)] << 26)
+    return int(rows_per_block) | ({1: 0, 2: 1, 4: 2, 8: 3}[int(parts)] << 24) | ({0: 0, 1: 1, 2: 2, 4: 3}[int(chunks)] << 26)
 
 
 class TimeStats(C.Structure):

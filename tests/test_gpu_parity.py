@@ -277,10 +277,14 @@ def test_colsweep_on_scattered_columns(torch):
     # columns into partial sums of its own; a row's sum is its partial sums added part by part -- the same from run to run and
     # inside the rounding bound, not the serial loop's bits
     scale = ob.csr_spmv(row_ptr, col_ind, np.abs(val), np.abs(x))
-    for rb, parts in ((2736, 2), (2736, 4), (1024, 4), (5120, 4), (10240, 2), (0, 4)):
+    # ... and parts = 8: one column part per XCD (workgroup b of a launch takes eighth b % 8 of the columns for the four whole strips of row
+    # group b / 8; the eight partial sums meet in scratch and are added by sweep_combine)
+    for rb, parts in ((2736, 2), (2736, 4), (1024, 4), (5120, 4), (10240, 2), (0, 4), (2736, 8), (20480, 8), (256, 8), (0, 8)):
         A.set_kernel(sm.CSR_KERNEL_COLSWEEP, sm.sweep_parts(rb, parts))
         got_rb, got_parts = A.get_kernel()[1] & 0xffffff, 1 << (A.get_kernel()[1] >> 24)
-        assert (got_rb, got_parts) == (rb or 2736, parts) and "%d column parts" % parts in A.describe()[0]
+        assert got_parts == parts and "%d column parts" % parts in A.describe()[0]
+        assert got_rb == (rb or (2736 if parts < 8 else 10940))        # (parts = 8, height chosen: two generations of 32 row groups)
+        assert A.launches() == (-(-(-(-rows // got_rb) * 8) // 256) + 1 if parts == 8 else A.launches())
         runs = []
         for _ in range(2):
             dy.fill_(float("nan"))
@@ -289,7 +293,7 @@ def test_colsweep_on_scattered_columns(torch):
             runs.append(dy.cpu().numpy())
         assert np.array_equal(runs[0], runs[1]) and np.all(np.abs(runs[0] - ref) <= 1e-12 * scale)
         assert not np.array_equal(runs[0], ref) or parts == 1            # (association differs: some row's last bit does)
-    for bad in (sm.sweep_parts(5124, 4), sm.sweep_parts(10244, 2), 3 << 24, sm.sweep_parts(2734, 2)):
+    for bad in (sm.sweep_parts(5124, 4), sm.sweep_parts(10244, 2), 1 << 28, sm.sweep_parts(2734, 2), sm.sweep_parts(20484, 8), sm.sweep_parts(252, 8)):
         with pytest.raises(sm.SmvpError):
             A.set_kernel(sm.CSR_KERNEL_COLSWEEP, bad)
     with pytest.raises(sm.SmvpError):
@@ -327,7 +331,7 @@ def test_colsweep_rows_that_meet_in_a_chunk(torch):
         assert np.array_equal(y, ref)
     # column parts: every part's chunks take their own turns; the sums are the serial ones up to the association part by part
     scale = row_scale(row_ptr, col_ind, val, x)
-    for rb, parts in ((1024, 2), (1024, 4), (5120, 4)):
+    for rb, parts in ((1024, 2), (1024, 4), (5120, 4), (1024, 8), (256, 8)):
         y = gpu_csr(torch, rows, cols, row_ptr, col_ind, val, x, sm.CSR_KERNEL_COLSWEEP, sm.sweep_parts(rb, parts))
         assert_close(y, ref, scale)
         assert np.array_equal(y, gpu_csr(torch, rows, cols, row_ptr, col_ind, val, x, sm.CSR_KERNEL_COLSWEEP, sm.sweep_parts(rb, parts)))
